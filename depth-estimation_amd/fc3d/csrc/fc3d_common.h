@@ -1,0 +1,68 @@
+// Shared helpers for the gfx950 kernels of libfc3d_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "fc3d.h"
+
+#define FC3D_LAUNCH_CHECK()                         \
+    do {                                            \
+        hipError_t e__ = hipGetLastError();         \
+        if (e__ != hipSuccess) return (int)e__;     \
+    } while (0)
+
+#define FC3D_HIP(call)                              \
+    do {                                            \
+        hipError_t e__ = (call);                    \
+        if (e__ != hipSuccess) return (int)e__;     \
+    } while (0)
+
+// Index and mask decisions must reproduce the reference's separately rounded fp32 ops:
+// never let the compiler fuse a*b+c on its own (fmaf is written out where a fused op is meant).
+#pragma clang fp contract(off)
+
+namespace fc3d {
+
+constexpr int kWave = 64;
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline bool aligned4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0; }
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Order-preserving map float -> uint32 (larger float <=> larger key); -0 is folded onto +0
+// so that ties between them are broken by position like torch.max does.
+__device__ __forceinline__ uint32_t float_to_key(float v) {
+    v = v + 0.0f;
+    uint32_t u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_to_float(uint32_t k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_max(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        T w = __shfl_xor(v, o, 64);
+        v = w > v ? w : v;
+    }
+    return v;
+}
+template <typename T>
+__device__ __forceinline__ T wave_min(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        T w = __shfl_xor(v, o, 64);
+        v = w < v ? w : v;
+    }
+    return v;
+}
+// Fixed-shape butterfly: every lane ends with the same sum, and the association order
+// depends only on lane ids, so the result is reproducible run to run.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+}  // namespace fc3d

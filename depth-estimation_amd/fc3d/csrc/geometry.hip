@@ -1,0 +1,950 @@
+// Pose reprojection, bilinear warp, forward-splat visibility and compositing
+// (geometry_pytorch.py) for gfx950.  All kernels are HBM-streaming: every lane owns four
+// neighbouring pixels of a row so that dense planes move as 16-byte accesses, the tiny
+// per-sample matrices sit in scalar registers, and the only irregular traffic is the
+// 4-tap gather (served by L1/L2 because warps are locally smooth) and the 1-byte splat.
+//
+// Arithmetic that decides an integer (floor/ceil/round of a projected coordinate) follows
+// the operation order of the reference's tensor ops exactly; explicit __fmul_rn/__fadd_rn
+// and fmaf keep the compiler from re-associating or contracting it.
+#include "fc3d_common.h"
+
+namespace fc3d {
+
+constexpr int NT = 256;
+
+// ---------------------------------------------------------------------------------------
+// per-sample matrices
+// ---------------------------------------------------------------------------------------
+__device__ inline bool invert4(const float* a, double* inv) {
+    double m[4][8];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            m[i][j] = (double)a[i * 4 + j];
+            m[i][4 + j] = (i == j) ? 1.0 : 0.0;
+        }
+    for (int c = 0; c < 4; ++c) {
+        int p = c;
+        double best = fabs(m[c][c]);
+        for (int r = c + 1; r < 4; ++r)
+            if (fabs(m[r][c]) > best) {
+                best = fabs(m[r][c]);
+                p = r;
+            }
+        if (p != c)
+            for (int j = 0; j < 8; ++j) {
+                double t = m[c][j];
+                m[c][j] = m[p][j];
+                m[p][j] = t;
+            }
+        const double d = 1.0 / m[c][c];
+        for (int j = 0; j < 8; ++j) m[c][j] *= d;
+        for (int r = 0; r < 4; ++r)
+            if (r != c) {
+                const double f = m[r][c];
+                for (int j = 0; j < 8; ++j) m[r][j] -= f * m[c][j];
+            }
+    }
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) inv[i * 4 + j] = m[i][4 + j];
+    return true;
+}
+
+// K*A for the 4x4 product torch evaluates with its small-matrix loop: products rounded
+// separately and summed left to right (no fused multiply-add).
+__device__ inline void intrinsics_times(const float K[16], const float* A, float* out) {
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            float s = __fmul_rn(K[i * 4 + 0], A[0 * 4 + j]);
+            s = __fadd_rn(s, __fmul_rn(K[i * 4 + 1], A[1 * 4 + j]));
+            s = __fadd_rn(s, __fmul_rn(K[i * 4 + 2], A[2 * 4 + j]));
+            s = __fadd_rn(s, __fmul_rn(K[i * 4 + 3], A[3 * 4 + j]));
+            out[i * 4 + j] = s;
+        }
+}
+
+__global__ void pose_transforms_kernel(const float* __restrict__ pose, const float* __restrict__ Kin, long k_sb,
+                                       int B, float* __restrict__ t_fwd, float* __restrict__ t_inv,
+                                       float* __restrict__ inv_out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float K[16];
+    for (int i = 0; i < 16; ++i) K[i] = Kin ? Kin[(long)b * k_sb + i] : 0.0f;
+    float A[16];
+    for (int i = 0; i < 16; ++i) A[i] = pose[(long)b * 16 + i];
+    float o[16];
+    if (t_fwd) {
+        intrinsics_times(K, A, o);
+        for (int i = 0; i < 16; ++i) t_fwd[(long)b * 16 + i] = o[i];
+    }
+    if (t_inv || inv_out) {
+        double inv[16];
+        invert4(A, inv);
+        float Af[16];
+        for (int i = 0; i < 16; ++i) Af[i] = (float)inv[i];
+        if (inv_out)
+            for (int i = 0; i < 16; ++i) inv_out[(long)b * 16 + i] = Af[i];
+        if (t_inv) {
+            intrinsics_times(K, Af, o);
+            for (int i = 0; i < 16; ++i) t_inv[(long)b * 16 + i] = o[i];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// projection
+// ---------------------------------------------------------------------------------------
+enum CoordLayout { kGeneric = 0, kPlanar4 = 1, kPixel4 = 2 };
+
+// Loads the homogeneous coordinates of 4 neighbouring pixels (x..x+3, row y): c[k][i] is
+// component k of pixel i.
+template <int LAYOUT>
+__device__ __forceinline__ void load_coord4(const float* __restrict__ base, long sc, long sh, long sw, int y,
+                                            int x, int W, float c[4][4]) {
+    if (LAYOUT == kPlanar4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float4 v = *reinterpret_cast<const float4*>(base + k * sc + (long)y * sh + x);
+            c[k][0] = v.x; c[k][1] = v.y; c[k][2] = v.z; c[k][3] = v.w;
+        }
+    } else if (LAYOUT == kPixel4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4 v = *reinterpret_cast<const float4*>(base + (long)y * sh + (long)(x + i) * 4);
+            c[0][i] = v.x; c[1][i] = v.y; c[2][i] = v.z; c[3][i] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                c[k][i] = (x + i < W) ? base[k * sc + (long)y * sh + (long)(x + i) * sw] : 1.0f;
+    }
+}
+
+// Row of T times a column.  torch.matmul([B,4,4],[B,4,HW]) runs a k-ordered fused
+// multiply-add chain (vendor sgemm) once 16*HW >= 400, and an unfused loop below that.
+template <bool FMA>
+__device__ __forceinline__ float row_dot(const float* t, float c0, float c1, float c2, float c3) {
+    if (FMA) {
+        float a = __fmul_rn(t[0], c0);
+        a = fmaf(t[1], c1, a);
+        a = fmaf(t[2], c2, a);
+        a = fmaf(t[3], c3, a);
+        return a;
+    } else {
+        float a = __fmul_rn(t[0], c0);
+        a = __fadd_rn(a, __fmul_rn(t[1], c1));
+        a = __fadd_rn(a, __fmul_rn(t[2], c2));
+        a = __fadd_rn(a, __fmul_rn(t[3], c3));
+        return a;
+    }
+}
+
+template <bool FMA>
+__device__ __forceinline__ void project_px(const float* T, float c0, float c1, float c2, float c3, float& gx,
+                                           float& gy) {
+    const float xu = row_dot<FMA>(T + 0, c0, c1, c2, c3);
+    const float yu = row_dot<FMA>(T + 4, c0, c1, c2, c3);
+    const float zu = row_dot<FMA>(T + 8, c0, c1, c2, c3);
+    const float den = __fadd_rn(zu, 1e-10f);
+    gx = xu / den;
+    gy = yu / den;
+}
+
+__device__ __forceinline__ void store_grid4(float* __restrict__ grid, long pix, int x, int W, bool vec,
+                                            const float gx[4], const float gy[4]) {
+    if (vec) {
+        float4* o = reinterpret_cast<float4*>(grid + pix * 2);
+        o[0] = make_float4(gx[0], gy[0], gx[1], gy[1]);
+        o[1] = make_float4(gx[2], gy[2], gx[3], gy[3]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (x + i < W) {
+                grid[(pix + i) * 2 + 0] = gx[i];
+                grid[(pix + i) * 2 + 1] = gy[i];
+            }
+    }
+}
+
+// Marks the pixels a projected point touches (gen_visible_mask).  The flat index is formed
+// in fp32 and only the flat index is range-checked, exactly like the reference, so an x
+// outside the row wraps into the neighbouring row.  Idempotent byte/float stores of "1"
+// need no atomics and give a bit-exact, order-independent mask.
+template <typename MaskT>
+__device__ __forceinline__ void mark(MaskT* __restrict__ m, float xi, float yi, float Wf, long HW, MaskT one) {
+    const float f = __fadd_rn(xi, __fmul_rn(yi, Wf));
+    if (!(fabsf(f) < 9.0e18f)) return;          // NaN / Inf / beyond int64: the reference's cast yields a negative index
+    const long idx = (long)f;
+    if (idx >= 0 && idx < HW) m[idx] = one;
+}
+
+template <typename MaskT>
+__device__ __forceinline__ void splat_px(MaskT* __restrict__ m, float gx, float gy, int W, long HW, int method,
+                                         MaskT one) {
+    const float Wf = (float)W;
+    if (method == 0) {
+        const float fx = floorf(gx), cx = ceilf(gx), fy = floorf(gy), cy = ceilf(gy);
+        mark(m, fx, fy, Wf, HW, one);
+        mark(m, fx, cy, Wf, HW, one);
+        mark(m, cx, fy, Wf, HW, one);
+        mark(m, cx, cy, Wf, HW, one);
+    } else {
+        mark(m, rintf(gx), rintf(gy), Wf, HW, one);
+    }
+}
+
+// coord_transform; with SPLAT also the 'all' visibility splat of warp_p2c's forward warp.
+template <int LAYOUT, bool FMA, bool SPLAT>
+__global__ __launch_bounds__(NT) void project_kernel(const float* __restrict__ coord, long sb, long sc, long sh,
+                                                     long sw, const float* __restrict__ Tm, int H, int W,
+                                                     float* __restrict__ grid, uint8_t* __restrict__ mask_u8) {
+    const int b = blockIdx.z;
+    const int qpr = (W + 3) >> 2;                       // 4-pixel groups per row
+    const long q4 = (long)blockIdx.x * NT + threadIdx.x;
+    if (q4 >= (long)H * qpr) return;
+    const int y = (int)(q4 / qpr);
+    const int x = (int)(q4 % qpr) * 4;
+    const float* T = Tm + (long)b * 16;
+    float c[4][4];
+    load_coord4<LAYOUT>(coord + (long)b * sb, sc, sh, sw, y, x, W, c);
+    float gx[4], gy[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) project_px<FMA>(T, c[0][i], c[1][i], c[2][i], c[3][i], gx[i], gy[i]);
+    const long HW = (long)H * W;
+    const long pix = (long)b * HW + (long)y * W + x;
+    store_grid4(grid, pix, x, W, LAYOUT != kGeneric, gx, gy);
+    if (SPLAT) {
+        uint8_t* m = mask_u8 + (long)b * HW;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (x + i < W) splat_px<uint8_t>(m, gx[i], gy[i], W, HW, 0, (uint8_t)1);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// bilinear sampling
+// ---------------------------------------------------------------------------------------
+struct Taps {
+    int x0, x1, y0, y1;
+    float wx0, wx1, wy0, wy1;
+};
+// Corners are clamped first and the weights are taken from the CLAMPED corners
+// (geometry_pytorch.py:136-145): out-of-image samples cancel to ~0, and an exact integer
+// coordinate on the last row/column gets weight 0.  fmaxf/fminf drop a NaN so indices stay
+// in range (the reference would raise on a NaN coordinate); the weights keep the NaN.
+__device__ __forceinline__ Taps make_taps(float gx, float gy, int Hs, int Ws) {
+    const float xm = (float)(Ws - 1), ym = (float)(Hs - 1);
+    const float fx = floorf(gx), fy = floorf(gy);
+    const float x0 = fminf(fmaxf(fx, 0.0f), xm), x1 = fminf(fmaxf(__fadd_rn(fx, 1.0f), 0.0f), xm);
+    const float y0 = fminf(fmaxf(fy, 0.0f), ym), y1 = fminf(fmaxf(__fadd_rn(fy, 1.0f), 0.0f), ym);
+    Taps t;
+    t.wx0 = __fsub_rn(x1, gx);
+    t.wx1 = __fsub_rn(gx, x0);
+    t.wy0 = __fsub_rn(y1, gy);
+    t.wy1 = __fsub_rn(gy, y0);
+    t.x0 = (int)x0; t.x1 = (int)x1; t.y0 = (int)y0; t.y1 = (int)y1;
+    return t;
+}
+
+__device__ __forceinline__ float blend(const Taps& t, float i00, float i01, float i10, float i11) {
+    // iab = image at (x_a, y_b); same products and left-to-right sum as geometry_pytorch.py:171-176
+    float o = __fmul_rn(__fmul_rn(t.wx0, t.wy0), i00);
+    o = __fadd_rn(o, __fmul_rn(__fmul_rn(t.wx0, t.wy1), i01));
+    o = __fadd_rn(o, __fmul_rn(__fmul_rn(t.wx1, t.wy0), i10));
+    o = __fadd_rn(o, __fmul_rn(__fmul_rn(t.wx1, t.wy1), i11));
+    return o;
+}
+
+// warp_p2c's inverse warp: project coord_c, sample the single-channel pattern, composite
+// with the visibility mask.
+template <int LAYOUT, bool FMA>
+__global__ __launch_bounds__(NT) void warp_sample_kernel(const float* __restrict__ coord, long sb, long sc, long sh,
+                                                         long sw, const float* __restrict__ Tm,
+                                                         const float* __restrict__ Ip,
+                                                         const uint8_t* __restrict__ mask_u8, int H, int W,
+                                                         float* __restrict__ grid, float* __restrict__ out) {
+    const int b = blockIdx.z;
+    const int qpr = (W + 3) >> 2;                       // 4-pixel groups per row
+    const long q4 = (long)blockIdx.x * NT + threadIdx.x;
+    if (q4 >= (long)H * qpr) return;
+    const int y = (int)(q4 / qpr);
+    const int x = (int)(q4 % qpr) * 4;
+    const float* T = Tm + (long)b * 16;
+    float c[4][4];
+    load_coord4<LAYOUT>(coord + (long)b * sb, sc, sh, sw, y, x, W, c);
+    const long HW = (long)H * W;
+    const long pix = (long)b * HW + (long)y * W + x;
+    const float* img = Ip + (long)b * HW;
+    float gx[4], gy[4], o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        project_px<FMA>(T, c[0][i], c[1][i], c[2][i], c[3][i], gx[i], gy[i]);
+        const Taps t = make_taps(gx[i], gy[i], H, W);
+        const float i00 = img[(long)t.y0 * W + t.x0], i01 = img[(long)t.y1 * W + t.x0];
+        const float i10 = img[(long)t.y0 * W + t.x1], i11 = img[(long)t.y1 * W + t.x1];
+        o[i] = blend(t, i00, i01, i10, i11);
+    }
+    store_grid4(grid, pix, x, W, LAYOUT != kGeneric, gx, gy);
+    if (LAYOUT != kGeneric) {
+        const uchar4 m = *reinterpret_cast<const uchar4*>(mask_u8 + pix);
+        *reinterpret_cast<float4*>(out + pix) = make_float4(o[0] * (float)m.x, o[1] * (float)m.y, o[2] * (float)m.z,
+                                                            o[3] * (float)m.w);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (x + i < W) out[pix + i] = o[i] * (float)mask_u8[pix + i];
+    }
+}
+
+// bilinear_sampler for any channel count; one lane per target pixel.
+__global__ __launch_bounds__(NT) void bilinear_fwd_kernel(const float* __restrict__ img,
+                                                          const float* __restrict__ grid,
+                                                          const uint8_t* __restrict__ mask_u8, int Hs, int Ws, int C,
+                                                          long npix_t, float* __restrict__ out) {
+    const int b = blockIdx.y;
+    const long p = (long)blockIdx.x * NT + threadIdx.x;
+    if (p >= npix_t) return;
+    const long q = (long)b * npix_t + p;
+    const float2 g = *reinterpret_cast<const float2*>(grid + q * 2);
+    const Taps t = make_taps(g.x, g.y, Hs, Ws);
+    const float* im = img + (long)b * Hs * Ws * C;
+    const long a00 = ((long)t.y0 * Ws + t.x0) * C, a01 = ((long)t.y1 * Ws + t.x0) * C;
+    const long a10 = ((long)t.y0 * Ws + t.x1) * C, a11 = ((long)t.y1 * Ws + t.x1) * C;
+    const float mk = mask_u8 ? (float)mask_u8[q] : 1.0f;
+    for (int c = 0; c < C; ++c) {
+        float o = blend(t, im[a00 + c], im[a01 + c], im[a10 + c], im[a11 + c]);
+        if (mask_u8) o = o * mk;
+        out[q * C + c] = o;
+    }
+}
+
+// d out / d grid.  floor and clamp carry no gradient, so only the four weights depend on the
+// coordinate: d/dx = wy0*(i10-i00) + wy1*(i11-i01), d/dy = wx0*(i01-i00) + wx1*(i11-i10).
+__global__ __launch_bounds__(NT) void bilinear_bwd_grid_kernel(const float* __restrict__ g_out,
+                                                               const float* __restrict__ img,
+                                                               const float* __restrict__ grid,
+                                                               const uint8_t* __restrict__ mask_u8, int Hs, int Ws,
+                                                               int C, long npix_t, float* __restrict__ g_grid) {
+    const int b = blockIdx.y;
+    const long p = (long)blockIdx.x * NT + threadIdx.x;
+    if (p >= npix_t) return;
+    const long q = (long)b * npix_t + p;
+    const float2 g = *reinterpret_cast<const float2*>(grid + q * 2);
+    const Taps t = make_taps(g.x, g.y, Hs, Ws);
+    const float* im = img + (long)b * Hs * Ws * C;
+    const long a00 = ((long)t.y0 * Ws + t.x0) * C, a01 = ((long)t.y1 * Ws + t.x0) * C;
+    const long a10 = ((long)t.y0 * Ws + t.x1) * C, a11 = ((long)t.y1 * Ws + t.x1) * C;
+    const float mk = mask_u8 ? (float)mask_u8[q] : 1.0f;
+    float dx = 0.0f, dy = 0.0f;
+    for (int c = 0; c < C; ++c) {
+        const float go = g_out[q * C + c] * mk;
+        const float i00 = im[a00 + c], i01 = im[a01 + c], i10 = im[a10 + c], i11 = im[a11 + c];
+        dx = fmaf(go, t.wy0 * (i10 - i00) + t.wy1 * (i11 - i01), dx);
+        dy = fmaf(go, t.wx0 * (i01 - i00) + t.wx1 * (i11 - i10), dy);
+    }
+    *reinterpret_cast<float2*>(g_grid + q * 2) = make_float2(dx, dy);
+}
+
+// ---------------------------------------------------------------------------------------
+// d out / d img for C == 1: scatter-add without global atomics
+//
+// Pass 1: each wavefront owns a 32x8 tile of target pixels.  It finds the bounding box of
+// the source pixels its taps touch (shuffle min/max), accumulates all taps into a private
+// LDS window of that box, and stores the window compactly ("slab") plus the box.
+// Pass 2: each workgroup owns a 64x16 tile of the source image and adds, in ascending tile
+// order, every slab whose box overlaps it -> the sum order is fixed, results reproducible.
+// Pass 3: tiles whose box did not fit the window (discontinuous warps) are added with
+// global float atomics.
+// ---------------------------------------------------------------------------------------
+constexpr int WT_X = 32, WT_Y = 8;       // wavefront tile
+constexpr int WIN_CAP = 2048;            // floats per window / slab
+
+struct TileMeta { int xmin, ymin, ww, wh; };   // ww = 0: empty, ww = -1: overflow
+
+struct PxTaps {
+    Taps t;
+    float v;
+    bool on;
+};
+
+__device__ __forceinline__ void load_tile_taps(const float* __restrict__ g_out, const float* __restrict__ grid,
+                                               const uint8_t* __restrict__ mask_u8, long tb, int Ht, int Wt, int Hs,
+                                               int Ws, int tx0, int ty0, int lane, PxTaps px[4]) {
+    const int x = tx0 + (lane & 31);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int y = ty0 + (lane >> 5) + 2 * k;
+        px[k].on = false;
+        px[k].v = 0.0f;
+        if (x < Wt && y < Ht) {
+            const long q = tb + (long)y * Wt + x;
+            const bool vis = mask_u8 ? (mask_u8[q] != 0) : true;
+            if (vis) {
+                const float2 g = *reinterpret_cast<const float2*>(grid + q * 2);
+                px[k].t = make_taps(g.x, g.y, Hs, Ws);
+                px[k].v = g_out[q];
+                px[k].on = true;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(NT) void bilinear_bwd_img_scatter_kernel(
+    const float* __restrict__ g_out, const float* __restrict__ grid, const uint8_t* __restrict__ mask_u8, int Hs,
+    int Ws, int Ht, int Wt, int tiles_x, int ntiles, TileMeta* __restrict__ meta, float* __restrict__ slab) {
+    __shared__ float win[NT / 64][WIN_CAP];
+    const int b = blockIdx.y;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int t = blockIdx.x * (NT / 64) + wv;
+    const bool live = t < ntiles;
+    const int tx0 = live ? (t % tiles_x) * WT_X : 0, ty0 = live ? (t / tiles_x) * WT_Y : Ht;
+    PxTaps px[4];
+    load_tile_taps(g_out, grid, mask_u8, (long)b * Ht * Wt, Ht, Wt, Hs, Ws, tx0, ty0, lane, px);
+    int xmin = 1 << 30, ymin = 1 << 30, xmax = -1, ymax = -1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (px[k].on) {
+            xmin = min(xmin, px[k].t.x0); xmax = max(xmax, px[k].t.x1);
+            ymin = min(ymin, px[k].t.y0); ymax = max(ymax, px[k].t.y1);
+        }
+    xmin = wave_min(xmin); ymin = wave_min(ymin);
+    xmax = wave_max(xmax); ymax = wave_max(ymax);
+    const bool empty = xmax < 0;
+    const int ww = empty ? 0 : xmax - xmin + 1, wh = empty ? 0 : ymax - ymin + 1;
+    const bool fits = (long)ww * wh <= WIN_CAP;
+    const int n = fits ? ww * wh : 0;
+    float* w = win[wv];
+    for (int i = lane; i < n; i += 64) w[i] = 0.0f;
+    __syncthreads();
+    if (fits && !empty) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (px[k].on) {
+                const Taps& tp = px[k].t;
+                const int r0 = (tp.y0 - ymin) * ww, r1 = (tp.y1 - ymin) * ww;
+                const int c0 = tp.x0 - xmin, c1 = tp.x1 - xmin;
+                atomicAdd(&w[r0 + c0], (tp.wx0 * tp.wy0) * px[k].v);
+                atomicAdd(&w[r1 + c0], (tp.wx0 * tp.wy1) * px[k].v);
+                atomicAdd(&w[r0 + c1], (tp.wx1 * tp.wy0) * px[k].v);
+                atomicAdd(&w[r1 + c1], (tp.wx1 * tp.wy1) * px[k].v);
+            }
+    }
+    __syncthreads();
+    if (live) {
+        const long tg = (long)b * ntiles + t;
+        float* s = slab + tg * WIN_CAP;
+        for (int i = lane; i < n; i += 64) s[i] = w[i];
+        if (lane == 0) {
+            TileMeta m;
+            m.xmin = xmin; m.ymin = ymin; m.ww = fits ? ww : -1; m.wh = wh;
+            if (empty) { m.xmin = 0; m.ymin = 0; m.ww = 0; m.wh = 0; }
+            meta[tg] = m;
+        }
+    }
+}
+
+constexpr int MT_X = 64, MT_Y = 16;      // merge tile of the source image
+
+__global__ __launch_bounds__(NT) void bilinear_bwd_img_merge_kernel(const TileMeta* __restrict__ meta,
+                                                                    const float* __restrict__ slab, int ntiles,
+                                                                    int Hs, int Ws, float* __restrict__ g_img) {
+    __shared__ TileMeta s_list[NT];
+    __shared__ int s_tile[NT];
+    __shared__ int s_wcnt[NT / 64];
+    const int b = blockIdx.z;
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    const int bx0 = blockIdx.x * MT_X, by0 = blockIdx.y * MT_Y;
+    const int x = bx0 + (tid & 15) * 4, y = by0 + (tid >> 4);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const TileMeta* mb = meta + (long)b * ntiles;
+    const float* sb = slab + (long)b * ntiles * WIN_CAP;
+    for (int base = 0; base < ntiles; base += NT) {
+        const int t = base + tid;
+        TileMeta m = {0, 0, 0, 0};
+        bool hit = false;
+        if (t < ntiles) {
+            m = mb[t];
+            hit = (m.ww > 0) && (m.xmin < bx0 + MT_X) && (m.xmin + m.ww > bx0) && (m.ymin < by0 + MT_Y) &&
+                  (m.ymin + m.wh > by0);
+        }
+        const unsigned long long bal = __ballot(hit);
+        if (lane == 0) s_wcnt[wv] = __popcll(bal);
+        __syncthreads();
+        int off = 0, total = 0;
+#pragma unroll
+        for (int i = 0; i < NT / 64; ++i) {
+            if (i < wv) off += s_wcnt[i];
+            total += s_wcnt[i];
+        }
+        if (hit) {
+            const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));
+            s_list[pos] = m;
+            s_tile[pos] = t;
+        }
+        __syncthreads();
+        for (int j = 0; j < total; ++j) {
+            const TileMeta e = s_list[j];
+            const int ry = y - e.ymin;
+            if (ry >= 0 && ry < e.wh) {
+                const float* row = sb + (long)s_tile[j] * WIN_CAP + ry * e.ww - e.xmin;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int cx = x + i - e.xmin;
+                    if (cx >= 0 && cx < e.ww) acc[i] += row[x + i];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (y < Hs) {
+        float* o = g_img + (long)b * Hs * Ws + (long)y * Ws + x;
+        if ((Ws & 3) == 0 && x < Ws) {
+            *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (x + i < Ws) o[i] = acc[i];
+        }
+    }
+}
+
+__global__ __launch_bounds__(NT) void bilinear_bwd_img_overflow_kernel(
+    const float* __restrict__ g_out, const float* __restrict__ grid, const uint8_t* __restrict__ mask_u8, int Hs,
+    int Ws, int Ht, int Wt, int tiles_x, int ntiles, const TileMeta* __restrict__ meta, float* __restrict__ g_img) {
+    const int b = blockIdx.y;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int t = blockIdx.x * (NT / 64) + wv;
+    if (t >= ntiles) return;
+    if (meta[(long)b * ntiles + t].ww != -1) return;
+    PxTaps px[4];
+    load_tile_taps(g_out, grid, mask_u8, (long)b * Ht * Wt, Ht, Wt, Hs, Ws, (t % tiles_x) * WT_X,
+                   (t / tiles_x) * WT_Y, lane, px);
+    float* o = g_img + (long)b * Hs * Ws;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (px[k].on) {
+            const Taps& tp = px[k].t;
+            atomicAdd(o + (long)tp.y0 * Ws + tp.x0, (tp.wx0 * tp.wy0) * px[k].v);
+            atomicAdd(o + (long)tp.y1 * Ws + tp.x0, (tp.wx0 * tp.wy1) * px[k].v);
+            atomicAdd(o + (long)tp.y0 * Ws + tp.x1, (tp.wx1 * tp.wy0) * px[k].v);
+            atomicAdd(o + (long)tp.y1 * Ws + tp.x1, (tp.wx1 * tp.wy1) * px[k].v);
+        }
+}
+
+// Any channel count: plain float atomics into a zeroed gradient image (the xyz sampling of
+// the capture simulator never needs this gradient; kept for completeness of the operator).
+__global__ __launch_bounds__(NT) void bilinear_bwd_img_atomic_kernel(const float* __restrict__ g_out,
+                                                                     const float* __restrict__ grid,
+                                                                     const uint8_t* __restrict__ mask_u8, int Hs,
+                                                                     int Ws, int C, long npix_t,
+                                                                     float* __restrict__ g_img) {
+    const int b = blockIdx.y;
+    const long p = (long)blockIdx.x * NT + threadIdx.x;
+    if (p >= npix_t) return;
+    const long q = (long)b * npix_t + p;
+    if (mask_u8 && mask_u8[q] == 0) return;
+    const float2 g = *reinterpret_cast<const float2*>(grid + q * 2);
+    const Taps t = make_taps(g.x, g.y, Hs, Ws);
+    float* o = g_img + (long)b * Hs * Ws * C;
+    const long a00 = ((long)t.y0 * Ws + t.x0) * C, a01 = ((long)t.y1 * Ws + t.x0) * C;
+    const long a10 = ((long)t.y0 * Ws + t.x1) * C, a11 = ((long)t.y1 * Ws + t.x1) * C;
+    for (int c = 0; c < C; ++c) {
+        const float v = g_out[q * C + c];
+        atomicAdd(o + a00 + c, (t.wx0 * t.wy0) * v);
+        atomicAdd(o + a01 + c, (t.wx0 * t.wy1) * v);
+        atomicAdd(o + a10 + c, (t.wx1 * t.wy0) * v);
+        atomicAdd(o + a11 + c, (t.wx1 * t.wy1) * v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// standalone visibility mask
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void visible_mask_kernel(const float* __restrict__ grid, int H, int W, int method,
+                                                          float* __restrict__ mask_f32,
+                                                          uint8_t* __restrict__ mask_u8) {
+    const int b = blockIdx.y;
+    const long HW = (long)H * W;
+    const long p = (long)blockIdx.x * NT + threadIdx.x;
+    if (p >= HW) return;
+    const float2 g = *reinterpret_cast<const float2*>(grid + ((long)b * HW + p) * 2);
+    if (mask_f32) splat_px<float>(mask_f32 + (long)b * HW, g.x, g.y, W, HW, method, 1.0f);
+    if (mask_u8) splat_px<uint8_t>(mask_u8 + (long)b * HW, g.x, g.y, W, HW, method, (uint8_t)1);
+}
+
+// ---------------------------------------------------------------------------------------
+// back-projection and the projector-depth -> camera-depth conversion
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void points_fwd_kernel(const float* __restrict__ z, const float* __restrict__ ray_x,
+                                                        const float* __restrict__ ray_y,
+                                                        const float* __restrict__ ray_dense, long ray_sb, int H, int W,
+                                                        float* __restrict__ out) {
+    const int b = blockIdx.z, y = blockIdx.y;
+    const int x = blockIdx.x * NT + threadIdx.x;
+    if (x >= W) return;
+    const long p = (long)y * W + x, q = (long)b * H * W + p;
+    float rx, ry, rz;
+    if (ray_dense) {
+        const float* r = ray_dense + (long)b * ray_sb + p * 3;
+        rx = r[0]; ry = r[1]; rz = r[2];
+    } else {
+        rx = ray_x[x]; ry = ray_y[y]; rz = 1.0f;
+    }
+    const float zz = z[q];
+    *reinterpret_cast<float4*>(out + q * 4) = make_float4(zz * rx, zz * ry, zz * rz, 1.0f);
+}
+
+__global__ __launch_bounds__(NT) void points_bwd_kernel(const float* __restrict__ g_out,
+                                                        const float* __restrict__ ray_x,
+                                                        const float* __restrict__ ray_y,
+                                                        const float* __restrict__ ray_dense, long ray_sb, int H, int W,
+                                                        float* __restrict__ g_z) {
+    const int b = blockIdx.z, y = blockIdx.y;
+    const int x = blockIdx.x * NT + threadIdx.x;
+    if (x >= W) return;
+    const long p = (long)y * W + x, q = (long)b * H * W + p;
+    float rx, ry, rz;
+    if (ray_dense) {
+        const float* r = ray_dense + (long)b * ray_sb + p * 3;
+        rx = r[0]; ry = r[1]; rz = r[2];
+    } else {
+        rx = ray_x[x]; ry = ray_y[y]; rz = 1.0f;
+    }
+    const float4 g = *reinterpret_cast<const float4*>(g_out + q * 4);
+    g_z[q] = (g.x * rx + g.y * ry) + g.z * rz;
+}
+
+__device__ __forceinline__ float zc_den(const float* a, float x, float y) {
+    return __fadd_rn(__fadd_rn(__fmul_rn(a[8], x), __fmul_rn(a[9], y)), a[10]);
+}
+
+__global__ __launch_bounds__(NT) void zp_to_zc_fwd_kernel(const float* __restrict__ zp, const float* __restrict__ xy,
+                                                          const float* __restrict__ inv, long HW,
+                                                          float* __restrict__ zc) {
+    const int b = blockIdx.y;
+    const long p = (long)blockIdx.x * NT + threadIdx.x;
+    if (p >= HW) return;
+    const long q = (long)b * HW + p;
+    const float* a = inv + (long)b * 16;
+    const float2 r = *reinterpret_cast<const float2*>(xy + q * 2);
+    zc[q] = __fsub_rn(zp[q], a[11]) / zc_den(a, r.x, r.y);
+}
+
+__global__ __launch_bounds__(NT) void zp_to_zc_bwd_kernel(const float* __restrict__ g_zc,
+                                                          const float* __restrict__ xy,
+                                                          const float* __restrict__ inv, long HW,
+                                                          float* __restrict__ g_zp) {
+    const int b = blockIdx.y;
+    const long p = (long)blockIdx.x * NT + threadIdx.x;
+    if (p >= HW) return;
+    const long q = (long)b * HW + p;
+    const float* a = inv + (long)b * 16;
+    const float2 r = *reinterpret_cast<const float2*>(xy + q * 2);
+    g_zp[q] = g_zc[q] / zc_den(a, r.x, r.y);
+}
+
+// Backward of coord_transform w.r.t. coord: with den = zu + 1e-10,
+//   g_xu = g_x/den, g_yu = g_y/den, g_zu = -(g_x*xu + g_y*yu)/den^2, g_coord = T^T g_u.
+template <int LAYOUT, bool FMA>
+__global__ __launch_bounds__(NT) void project_bwd_kernel(const float* __restrict__ g_grid,
+                                                         const float* __restrict__ coord, long sb, long sc, long sh,
+                                                         long sw, const float* __restrict__ Tm, int H, int W,
+                                                         float* __restrict__ g_coord) {
+    const int b = blockIdx.z;
+    const int qpr = (W + 3) >> 2;                       // 4-pixel groups per row
+    const long q4 = (long)blockIdx.x * NT + threadIdx.x;
+    if (q4 >= (long)H * qpr) return;
+    const int y = (int)(q4 / qpr);
+    const int x = (int)(q4 % qpr) * 4;
+    const float* T = Tm + (long)b * 16;
+    float c[4][4];
+    load_coord4<LAYOUT>(coord + (long)b * sb, sc, sh, sw, y, x, W, c);
+    const long HW = (long)H * W;
+    const long pix = (long)b * HW + (long)y * W + x;
+    float go[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (x + i >= W) continue;
+        const float xu = row_dot<FMA>(T + 0, c[0][i], c[1][i], c[2][i], c[3][i]);
+        const float yu = row_dot<FMA>(T + 4, c[0][i], c[1][i], c[2][i], c[3][i]);
+        const float zu = row_dot<FMA>(T + 8, c[0][i], c[1][i], c[2][i], c[3][i]);
+        const float den = zu + 1e-10f;
+        const float ggx = g_grid[(pix + i) * 2 + 0], ggy = g_grid[(pix + i) * 2 + 1];
+        const float gxu = ggx / den, gyu = ggy / den;
+        const float gzu = -(ggx * xu + ggy * yu) / (den * den);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) go[k][i] = T[0 + k] * gxu + T[4 + k] * gyu + T[8 + k] * gzu;
+    }
+    float* o = g_coord + (long)b * 4 * HW + (long)y * W + x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (LAYOUT != kGeneric) {
+            *reinterpret_cast<float4*>(o + k * HW) = make_float4(go[k][0], go[k][1], go[k][2], go[k][3]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (x + i < W) o[k * HW + i] = go[k][i];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// host helpers
+// ---------------------------------------------------------------------------------------
+static int pick_layout(const float* coord, int64_t sc, int64_t sh, int64_t sw, int W, const float* out_a,
+                       const float* out_b) {
+    const bool outs_ok = (W % 4 == 0) && aligned16(out_a) && (!out_b || aligned16(out_b));
+    if (!outs_ok || !aligned16(coord)) return kGeneric;
+    if (sw == 1 && sh % 4 == 0 && sc % 4 == 0) return kPlanar4;
+    if (sc == 1 && sw == 4 && sh % 4 == 0) return kPixel4;
+    return kGeneric;
+}
+
+static int check_img(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return FC3D_EINVAL;
+    if ((long)B * H * W >= (1L << 31) || B > 65535 || H > 65535) return FC3D_ERANGE;
+    return FC3D_OK;
+}
+
+// 16*H*W >= 400 selects torch's sgemm (fused multiply-add) path for [B,4,4]x[B,4,HW].
+static inline bool use_fma(int H, int W) { return 16L * H * W >= 400; }
+
+#define FC3D_DISPATCH_LAYOUT(KERNEL, layout, fma, ...)                                                     \
+    do {                                                                                                   \
+        if (fma) {                                                                                         \
+            if (layout == kPlanar4) hipLaunchKernelGGL((KERNEL<kPlanar4, true, ##__VA_ARGS__>), g, blk, 0, s, ARGS); \
+            else if (layout == kPixel4) hipLaunchKernelGGL((KERNEL<kPixel4, true, ##__VA_ARGS__>), g, blk, 0, s, ARGS); \
+            else hipLaunchKernelGGL((KERNEL<kGeneric, true, ##__VA_ARGS__>), g, blk, 0, s, ARGS);           \
+        } else {                                                                                           \
+            if (layout == kPlanar4) hipLaunchKernelGGL((KERNEL<kPlanar4, false, ##__VA_ARGS__>), g, blk, 0, s, ARGS); \
+            else if (layout == kPixel4) hipLaunchKernelGGL((KERNEL<kPixel4, false, ##__VA_ARGS__>), g, blk, 0, s, ARGS); \
+            else hipLaunchKernelGGL((KERNEL<kGeneric, false, ##__VA_ARGS__>), g, blk, 0, s, ARGS);          \
+        }                                                                                                  \
+    } while (0)
+
+}  // namespace fc3d
+
+using namespace fc3d;
+
+extern "C" int fc3d_pose_transforms(void* stream, const float* pose, const float* K, int64_t k_sb, int B,
+                                    float* t_fwd_out, float* t_inv_out, float* inv_out) {
+    if (!pose || B <= 0) return FC3D_EINVAL;
+    if (!K && (t_fwd_out || t_inv_out)) return FC3D_EINVAL;
+    hipLaunchKernelGGL(pose_transforms_kernel, dim3(cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, pose, K,
+                       (long)k_sb, B, t_fwd_out, t_inv_out, inv_out);
+    FC3D_LAUNCH_CHECK();
+    return FC3D_OK;
+}
+
+extern "C" int fc3d_project_fwd(void* stream, const float* coord, int64_t sb, int64_t sc, int64_t sh, int64_t sw,
+                                const float* T, int B, int H, int W, float* grid_out) {
+    if (!coord || !T || !grid_out) return FC3D_EINVAL;
+    if (int e = check_img(B, H, W)) return e;
+    const int layout = pick_layout(coord, sc, sh, sw, W, grid_out, nullptr);
+    const bool fma = use_fma(H, W);
+    dim3 g(cdiv((long)H * cdiv(W, 4), NT), 1, B), blk(NT);
+    hipStream_t s = (hipStream_t)stream;
+    uint8_t* nomask = nullptr;
+#define ARGS coord, (long)sb, (long)sc, (long)sh, (long)sw, T, H, W, grid_out, nomask
+    FC3D_DISPATCH_LAYOUT(project_kernel, layout, fma, false);
+#undef ARGS
+    FC3D_LAUNCH_CHECK();
+    return FC3D_OK;
+}
+
+extern "C" int fc3d_project_bwd(void* stream, const float* g_grid, const float* coord, int64_t sb, int64_t sc,
+                                int64_t sh, int64_t sw, const float* T, int B, int H, int W, float* g_coord) {
+    if (!g_grid || !coord || !T || !g_coord) return FC3D_EINVAL;
+    if (int e = check_img(B, H, W)) return e;
+    const int layout = pick_layout(coord, sc, sh, sw, W, g_coord, nullptr);
+    const bool fma = use_fma(H, W);
+    dim3 g(cdiv((long)H * cdiv(W, 4), NT), 1, B), blk(NT);
+    hipStream_t s = (hipStream_t)stream;
+#define ARGS g_grid, coord, (long)sb, (long)sc, (long)sh, (long)sw, T, H, W, g_coord
+    FC3D_DISPATCH_LAYOUT(project_bwd_kernel, layout, fma);
+#undef ARGS
+    FC3D_LAUNCH_CHECK();
+    return FC3D_OK;
+}
+
+extern "C" int fc3d_bilinear_fwd(void* stream, const float* img, const float* grid, const uint8_t* mask_u8, int B,
+                                 int Hs, int Ws, int C, int Ht, int Wt, float* out) {
+    if (!img || !grid || !out || C <= 0) return FC3D_EINVAL;
+    if (int e = check_img(B, Hs, Ws)) return e;
+    if (int e = check_img(B, Ht, Wt)) return e;
+    if ((long)B * Hs * Ws * C >= (1L << 31) || (long)B * Ht * Wt * C >= (1L << 31)) return FC3D_ERANGE;
+    if (!aligned4(img) || (reinterpret_cast<uintptr_t>(grid) & 7u)) return FC3D_EALIGN;
+    const long np = (long)Ht * Wt;
+    hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(cdiv(np, NT), B), dim3(NT), 0, (hipStream_t)stream, img, grid, mask_u8,
+                       Hs, Ws, C, np, out);
+    FC3D_LAUNCH_CHECK();
+    return FC3D_OK;
+}
+
+extern "C" int fc3d_bilinear_bwd_grid(void* stream, const float* g_out, const float* img, const float* grid,
+                                      const uint8_t* mask_u8, int B, int Hs, int Ws, int C, int Ht, int Wt,
+                                      float* g_grid) {
+    if (!g_out || !img || !grid || !g_grid || C <= 0) return FC3D_EINVAL;
+    if (int e = check_img(B, Hs, Ws)) return e;
+    if (int e = check_img(B, Ht, Wt)) return e;
+    if ((long)B * Hs * Ws * C >= (1L << 31) || (long)B * Ht * Wt * C >= (1L << 31)) return FC3D_ERANGE;
+    if ((reinterpret_cast<uintptr_t>(grid) & 7u) || (reinterpret_cast<uintptr_t>(g_grid) & 7u)) return FC3D_EALIGN;
+    const long np = (long)Ht * Wt;
+    hipLaunchKernelGGL(bilinear_bwd_grid_kernel, dim3(cdiv(np, NT), B), dim3(NT), 0, (hipStream_t)stream, g_out, img,
+                       grid, mask_u8, Hs, Ws, C, np, g_grid);
+    FC3D_LAUNCH_CHECK();
+    return FC3D_OK;
+}
+
+static inline int wave_tiles(int Ht, int Wt, int* tiles_x) {
+    *tiles_x = cdiv(Wt, WT_X);
+    return *tiles_x * cdiv(Ht, WT_Y);
+}
+
+extern "C" size_t fc3d_bilinear_bwd_img_workspace(int B, int Hs, int Ws, int C, int Ht, int Wt) {
+    if (B <= 0 || Hs <= 0 || Ws <= 0 || Ht <= 0 || Wt <= 0 || C != 1) return 0;
+    int tx;
+    const size_t nt = (size_t)B * wave_tiles(Ht, Wt, &tx);
+    return nt * sizeof(TileMeta) + nt * WIN_CAP * sizeof(float);
+}
+
+extern "C" int fc3d_bilinear_bwd_img(void* stream, const float* g_out, const float* grid, const uint8_t* mask_u8,
+                                     int B, int Hs, int Ws, int C, int Ht, int Wt, void* workspace, float* g_img) {
+    if (!g_out || !grid || !g_img || C <= 0) return FC3D_EINVAL;
+    if (int e = check_img(B, Hs, Ws)) return e;
+    if (int e = check_img(B, Ht, Wt)) return e;
+    if ((long)B * Hs * Ws * C >= (1L << 31) || (long)B * Ht * Wt * C >= (1L << 31)) return FC3D_ERANGE;
+    if (reinterpret_cast<uintptr_t>(grid) & 7u) return FC3D_EALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    if (C != 1) {
+        FC3D_HIP(hipMemsetAsync(g_img, 0, (size_t)B * Hs * Ws * C * sizeof(float), s));
+        const long np = (long)Ht * Wt;
+        hipLaunchKernelGGL(bilinear_bwd_img_atomic_kernel, dim3(cdiv(np, NT), B), dim3(NT), 0, s, g_out, grid, mask_u8,
+                           Hs, Ws, C, np, g_img);
+        FC3D_LAUNCH_CHECK();
+        return FC3D_OK;
+    }
+    if (!workspace || !aligned16(workspace)) return workspace ? FC3D_EALIGN : FC3D_EINVAL;
+    int tiles_x;
+    const int ntiles = wave_tiles(Ht, Wt, &tiles_x);
+    TileMeta* meta = (TileMeta*)workspace;
+    float* slab = (float*)(meta + (size_t)B * ntiles);
+    const dim3 gs(cdiv(ntiles, NT / 64), B), blk(NT);
+    hipLaunchKernelGGL(bilinear_bwd_img_scatter_kernel, gs, blk, 0, s, g_out, grid, mask_u8, Hs, Ws, Ht, Wt, tiles_x,
+                       ntiles, meta, slab);
+    FC3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bilinear_bwd_img_merge_kernel, dim3(cdiv(Ws, MT_X), cdiv(Hs, MT_Y), B), blk, 0, s,
+                       (const TileMeta*)meta, (const float*)slab, ntiles, Hs, Ws, g_img);
+    FC3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bilinear_bwd_img_overflow_kernel, gs, blk, 0, s, g_out, grid, mask_u8, Hs, Ws, Ht, Wt, tiles_x,
+                       ntiles, (const TileMeta*)meta, g_img);
+    FC3D_LAUNCH_CHECK();
+    return FC3D_OK;
+}
+
+extern "C" int fc3d_visible_mask(void* stream, const float* grid, int B, int H, int W, int method, float* mask_f32,
+                                 uint8_t* mask_u8) {
+    if (!grid || (!mask_f32 && !mask_u8) || (method != 0 && method != 1)) return FC3D_EINVAL;
+    if (int e = check_img(B, H, W)) return e;
+    if (reinterpret_cast<uintptr_t>(grid) & 7u) return FC3D_EALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = (size_t)B * H * W;
+    if (mask_f32) FC3D_HIP(hipMemsetAsync(mask_f32, 0, n * sizeof(float), s));
+    if (mask_u8) FC3D_HIP(hipMemsetAsync(mask_u8, 0, n, s));
+    const long HW = (long)H * W;
+    hipLaunchKernelGGL(visible_mask_kernel, dim3(cdiv(HW, NT), B), dim3(NT), 0, s, grid, H, W, method, mask_f32,
+                       mask_u8);
+    FC3D_LAUNCH_CHECK();
+    return FC3D_OK;
+}
+
+extern "C" int fc3d_warp_p2c_fwd(void* stream, const float* Ip, const float* coord_p, int64_t p_sb, int64_t p_sc,
+                                 int64_t p_sh, int64_t p_sw, const float* coord_c, int64_t c_sb, int64_t c_sc,
+                                 int64_t c_sh, int64_t c_sw, const float* T_p2c, const float* T_c2p, int B, int H,
+                                 int W, float* Ic_masked, float* grid_p2c, float* grid_c2p, uint8_t* mask_u8) {
+    if (!Ip || !coord_p || !coord_c || !T_p2c || !T_c2p || !Ic_masked || !grid_p2c || !grid_c2p || !mask_u8)
+        return FC3D_EINVAL;
+    if (int e = check_img(B, H, W)) return e;
+    hipStream_t s = (hipStream_t)stream;
+    const bool fma = use_fma(H, W);
+    dim3 g(cdiv((long)H * cdiv(W, 4), NT), 1, B), blk(NT);
+    FC3D_HIP(hipMemsetAsync(mask_u8, 0, (size_t)B * H * W, s));
+    {
+        const int layout = pick_layout(coord_p, p_sc, p_sh, p_sw, W, grid_p2c, nullptr);
+#define ARGS coord_p, (long)p_sb, (long)p_sc, (long)p_sh, (long)p_sw, T_p2c, H, W, grid_p2c, mask_u8
+        FC3D_DISPATCH_LAYOUT(project_kernel, layout, fma, true);
+#undef ARGS
+        FC3D_LAUNCH_CHECK();
+    }
+    {
+        int layout = pick_layout(coord_c, c_sc, c_sh, c_sw, W, grid_c2p, Ic_masked);
+        if (!aligned4(mask_u8)) layout = kGeneric;
+#define ARGS coord_c, (long)c_sb, (long)c_sc, (long)c_sh, (long)c_sw, T_c2p, Ip, (const uint8_t*)mask_u8, H, W, grid_c2p, Ic_masked
+        FC3D_DISPATCH_LAYOUT(warp_sample_kernel, layout, fma);
+#undef ARGS
+        FC3D_LAUNCH_CHECK();
+    }
+    return FC3D_OK;
+}
+
+extern "C" int fc3d_points_fwd(void* stream, const float* z, const float* ray_x, const float* ray_y,
+                               const float* ray_dense, int64_t ray_sb, int B, int H, int W, float* out) {
+    if (!z || !out || (!ray_dense && (!ray_x || !ray_y))) return FC3D_EINVAL;
+    if (int e = check_img(B, H, W)) return e;
+    if (!aligned16(out)) return FC3D_EALIGN;
+    hipLaunchKernelGGL(points_fwd_kernel, dim3(cdiv(W, NT), H, B), dim3(NT), 0, (hipStream_t)stream, z, ray_x, ray_y,
+                       ray_dense, (long)ray_sb, H, W, out);
+    FC3D_LAUNCH_CHECK();
+    return FC3D_OK;
+}
+
+extern "C" int fc3d_points_bwd(void* stream, const float* g_out, const float* ray_x, const float* ray_y,
+                               const float* ray_dense, int64_t ray_sb, int B, int H, int W, float* g_z) {
+    if (!g_out || !g_z || (!ray_dense && (!ray_x || !ray_y))) return FC3D_EINVAL;
+    if (int e = check_img(B, H, W)) return e;
+    if (!aligned16(g_out)) return FC3D_EALIGN;
+    hipLaunchKernelGGL(points_bwd_kernel, dim3(cdiv(W, NT), H, B), dim3(NT), 0, (hipStream_t)stream, g_out, ray_x,
+                       ray_y, ray_dense, (long)ray_sb, H, W, g_z);
+    FC3D_LAUNCH_CHECK();
+    return FC3D_OK;
+}
+
+extern "C" int fc3d_zp_to_zc_fwd(void* stream, const float* zp, const float* xy, const float* inv, int B, int H, int W,
+                                 float* zc) {
+    if (!zp || !xy || !inv || !zc) return FC3D_EINVAL;
+    if (int e = check_img(B, H, W)) return e;
+    if (reinterpret_cast<uintptr_t>(xy) & 7u) return FC3D_EALIGN;
+    const long HW = (long)H * W;
+    hipLaunchKernelGGL(zp_to_zc_fwd_kernel, dim3(cdiv(HW, NT), B), dim3(NT), 0, (hipStream_t)stream, zp, xy, inv, HW,
+                       zc);
+    FC3D_LAUNCH_CHECK();
+    return FC3D_OK;
+}
+
+extern "C" int fc3d_zp_to_zc_bwd(void* stream, const float* g_zc, const float* xy, const float* inv, int B, int H,
+                                 int W, float* g_zp) {
+    if (!g_zc || !xy || !inv || !g_zp) return FC3D_EINVAL;
+    if (int e = check_img(B, H, W)) return e;
+    if (reinterpret_cast<uintptr_t>(xy) & 7u) return FC3D_EALIGN;
+    const long HW = (long)H * W;
+    hipLaunchKernelGGL(zp_to_zc_bwd_kernel, dim3(cdiv(HW, NT), B), dim3(NT), 0, (hipStream_t)stream, g_zc, xy, inv, HW,
+                       g_zp);
+    FC3D_LAUNCH_CHECK();
+    return FC3D_OK;
+}
+
+extern "C" int fc3d_version(void) { return FC3D_VERSION; }
+
+extern "C" const char* fc3d_status_string(int status) {
+    switch (status) {
+        case FC3D_OK: return "ok";
+        case FC3D_EINVAL: return "invalid argument (null pointer or non-positive size)";
+        case FC3D_ERANGE: return "size out of the range the kernels index";
+        case FC3D_EALIGN: return "pointer not aligned to its element type";
+        default: break;
+    }
+    if (status > 0) return hipGetErrorString((hipError_t)status);
+    return "unknown status";
+}

@@ -1,0 +1,479 @@
+// Depth-layered PSF blur (codePattern, optics_pytorch.py:71-121) for gfx950.
+//
+// Forward: one workgroup owns a 64x16 output tile.  It derives each pixel's depth layer
+// from z on the fly (no [B,H,W,L] one-hot mask ever exists), stages channel 0 of the
+// pattern with its K-1 halo and the PSFs of only the layers present in the tile into LDS,
+// and lets every lane accumulate 4 neighbouring outputs with a sliding register window.
+// The per-image maximum is found without atomics: each tile writes one packed 64-bit key
+// (ordered value | position priority) and the normalisation pass reduces an image's keys.
+//
+// Backward (w.r.t. pattern[...,0]): a deterministic two-level sum gives sum(g*out) per
+// image, then the transposed convolution is evaluated in gather form: every output pixel
+// walks its K x K neighbours p and uses the PSF of *p's* layer.
+#include "fc3d_common.h"
+
+namespace fc3d {
+
+constexpr int TX = 64;    // tile width  (16 lanes x 4 pixels)
+constexpr int TY = 16;    // tile height
+constexpr int NT = 256;   // threads per workgroup
+constexpr int kLdsBudget = 60 * 1024;
+
+// All fp32, one rounding per line, matching torch's tensor ops on the CPU:
+// reciprocal(z) - 1/z0, * coeff, / step (a true division), round-half-even.
+__device__ __forceinline__ int layer_of(float z, const fc3d_layer_grid& g) {
+    float r = 1.0f / z;
+    float d = r - g.inv_z0;
+    float wm = g.coeff * d;
+    float n = wm / g.step;
+    float rr = rintf(n);
+    float lf = rintf(rr - g.centre0);
+    bool ok = (lf >= 0.0f) && (lf < (float)g.n_layers) && (fabsf(rr - (g.centre0 + lf)) < 0.01f);
+    return ok ? (int)lf : -1;
+}
+
+struct TileGeom {
+    int th, tw, S;   // staged rows, staged columns, LDS row stride (floats)
+};
+__host__ __device__ inline TileGeom tile_geom(int Kh, int Kw) {
+    TileGeom t;
+    t.th = TY + Kh - 1;
+    t.tw = TX + Kw - 1;
+    t.S = (t.tw + 1 + 3) & ~3;   // +1: the sliding window pre-loads one column past the tile
+    return t;
+}
+
+__device__ __forceinline__ void block_minmax(int lmin, int lmax, int* s_min, int* s_max) {
+    lmin = wave_min(lmin);
+    lmax = wave_max(lmax);
+    if (threadIdx.x == 0) {
+        *s_min = 1 << 30;
+        *s_max = -1;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(s_min, lmin);
+        atomicMax(s_max, lmax);
+    }
+    __syncthreads();
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(NT) void code_pattern_fwd_kernel(
+    const float* __restrict__ pat0, long sb, long sh, long sw, const float* __restrict__ z,
+    const float* __restrict__ psf, int H, int W, int Kh, int Kw, int conv, int cap_layers,
+    fc3d_layer_grid lg, float* __restrict__ raw, uint8_t* __restrict__ layer_u8,
+    unsigned long long* __restrict__ tilekey) {
+    extern __shared__ float smem[];
+    __shared__ int s_lmin, s_lmax;
+    __shared__ unsigned long long s_key[NT / 64];
+
+    const int b = blockIdx.z;
+    const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int x = x0 + 4 * tx, y = y0 + ty;
+    const long img = (long)b * H * W;
+    const int KK = Kh * Kw;
+
+    // -- 1. depth layer of my four pixels
+    float zv[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+    bool inb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) inb[i] = (y < H) && (x + i < W);
+    if (VEC) {
+        if (inb[0]) {
+            float4 v = *reinterpret_cast<const float4*>(z + img + (long)y * W + x);
+            zv[0] = v.x; zv[1] = v.y; zv[2] = v.z; zv[3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (inb[i]) zv[i] = z[img + (long)y * W + x + i];
+    }
+    int lay[4];
+    int lmin = 1 << 30, lmax = -1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        lay[i] = inb[i] ? layer_of(zv[i], lg) : -1;
+        if (lay[i] >= 0) {
+            lmin = min(lmin, lay[i]);
+            lmax = max(lmax, lay[i]);
+        }
+    }
+
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (conv) {
+        const TileGeom tg = tile_geom(Kh, Kw);
+        float* tile = smem;
+        float* wts = smem + tg.th * tg.S;
+        block_minmax(lmin, lmax, &s_lmin, &s_lmax);
+        const int bl0 = s_lmin;
+        const int nl = (s_lmax >= bl0) ? min(s_lmax - bl0 + 1, cap_layers) : 0;
+
+        // -- 2. stage pattern tile + halo (zero 'same' padding) and the PSFs of layers bl0..bl0+nl-1
+        const int padh = (Kh - 1) / 2, padw = (Kw - 1) / 2;
+        const float* pimg = pat0 + (long)b * sb;
+        for (int r = tid / 64; r < tg.th; r += NT / 64) {
+            const int gy = y0 - padh + r;
+            const bool rowok = (gy >= 0) && (gy < H);
+            for (int c = tid & 63; c < tg.S; c += 64) {
+                const int gx = x0 - padw + c;
+                float v = 0.0f;
+                if (rowok && c < tg.tw && gx >= 0 && gx < W) v = pimg[(long)gy * sh + (long)gx * sw];
+                tile[r * tg.S + c] = v;
+            }
+        }
+        const float* wsrc = psf + (long)bl0 * KK;
+        for (int i = tid; i < nl * KK; i += NT) wts[i] = wsrc[i];
+        __syncthreads();
+
+        // -- 3. accumulate
+        const bool any = (lay[0] >= 0) | (lay[1] >= 0) | (lay[2] >= 0) | (lay[3] >= 0);
+        const int l0 = lay[0];
+        const bool uniform = (l0 >= 0) && (lay[1] == l0) && (lay[2] == l0) && (lay[3] == l0) && (l0 - bl0 < nl);
+        if (uniform) {
+            const float* wl = wts + (l0 - bl0) * KK;
+            for (int dy = 0; dy < Kh; ++dy) {
+                const float* trow = tile + (ty + dy) * tg.S + 4 * tx;
+                const float* wrow = wl + dy * Kw;
+                float s0 = trow[0], s1 = trow[1], s2 = trow[2], s3 = trow[3];
+                for (int dx = 0; dx < Kw; ++dx) {
+                    const float w = wrow[dx];
+                    const float nx = trow[dx + 4];
+                    acc[0] = fmaf(w, s0, acc[0]);
+                    acc[1] = fmaf(w, s1, acc[1]);
+                    acc[2] = fmaf(w, s2, acc[2]);
+                    acc[3] = fmaf(w, s3, acc[3]);
+                    s0 = s1; s1 = s2; s2 = s3; s3 = nx;
+                }
+            }
+        } else if (any) {
+            const float* wp[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int l = max(lay[i], 0);
+                // layers beyond the staged range (tile spans more layers than fit in LDS) come from global
+                wp[i] = (l >= bl0 && l - bl0 < nl) ? (wts + (l - bl0) * KK) : (psf + (long)l * KK);
+            }
+            for (int dy = 0; dy < Kh; ++dy) {
+                const float* trow = tile + (ty + dy) * tg.S + 4 * tx;
+                for (int dx = 0; dx < Kw; ++dx) {
+                    const int k = dy * Kw + dx;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i] = fmaf(wp[i][k], trow[dx + i], acc[i]);
+                }
+            }
+        }
+    } else {
+        // is_conv_psf=False: the pattern itself, gated by the in-range mask
+        const float* pimg = pat0 + (long)b * sb;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (inb[i]) acc[i] = pimg[(long)y * sh + (long)(x + i) * sw];
+    }
+
+    // -- 4. gate by the layer mask (multiply, so a non-finite blur still poisons the pixel
+    //       as conv*0 does in the reference), store, and publish the tile's max key
+    unsigned long long key = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        acc[i] = acc[i] * (lay[i] >= 0 ? 1.0f : 0.0f);
+        if (inb[i]) {
+            const uint32_t pos = 0xffffffffu - (uint32_t)((x + i) * H + y);   // first w, then first h
+            const unsigned long long k = ((unsigned long long)float_to_key(acc[i]) << 32) | pos;
+            key = k > key ? k : key;
+        }
+    }
+    if (VEC) {
+        if (inb[0]) {
+            *reinterpret_cast<float4*>(raw + img + (long)y * W + x) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            if (layer_u8)
+                *reinterpret_cast<uchar4*>(layer_u8 + img + (long)y * W + x) =
+                    make_uchar4((uint8_t)lay[0], (uint8_t)lay[1], (uint8_t)lay[2], (uint8_t)lay[3]);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (inb[i]) {
+                raw[img + (long)y * W + x + i] = acc[i];
+                if (layer_u8) layer_u8[img + (long)y * W + x + i] = (uint8_t)lay[i];
+            }
+    }
+    key = wave_max(key);
+    if ((tid & 63) == 0) s_key[tid >> 6] = key;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long k = s_key[0];
+#pragma unroll
+        for (int i = 1; i < NT / 64; ++i) k = s_key[i] > k ? s_key[i] : k;
+        tilekey[(long)b * gridDim.x * gridDim.y + blockIdx.y * gridDim.x + blockIdx.x] = k;
+    }
+}
+
+__device__ __forceinline__ unsigned long long block_max_key(const unsigned long long* keys, int n,
+                                                            unsigned long long* s_red) {
+    unsigned long long k = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        unsigned long long v = keys[i];
+        k = v > k ? v : k;
+    }
+    k = wave_max(k);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = k;
+    __syncthreads();
+    k = s_red[0];
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) k = s_red[i] > k ? s_red[i] : k;
+    return k;
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(NT) void code_pattern_norm_kernel(
+    const float* __restrict__ raw, const unsigned long long* __restrict__ tilekey, int ntiles, int H, int W,
+    float* __restrict__ out, float* __restrict__ max_out, int* __restrict__ argmax_out) {
+    __shared__ unsigned long long s_red[NT / 64];
+    const int b = blockIdx.y;
+    const unsigned long long key = block_max_key(tilekey + (long)b * ntiles, ntiles, s_red);
+    const float m = key_to_float((uint32_t)(key >> 32));
+    const float den = m + 1e-10f;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const uint32_t pos = 0xffffffffu - (uint32_t)(key & 0xffffffffu);
+        max_out[b] = m;
+        argmax_out[b] = (int)(pos % (uint32_t)H) * W + (int)(pos / (uint32_t)H);
+    }
+    const long HW = (long)H * W;
+    const long base = (long)b * HW;
+    if (VEC) {
+        const long i = ((long)blockIdx.x * NT + threadIdx.x) * 4;
+        if (i < HW) {
+            float4 v = *reinterpret_cast<const float4*>(raw + base + i);
+            v.x = v.x / den; v.y = v.y / den; v.z = v.z / den; v.w = v.w / den;
+            *reinterpret_cast<float4*>(out + base + i) = v;
+        }
+    } else {
+        const long i0 = ((long)blockIdx.x * NT + threadIdx.x) * 4;
+        for (int k = 0; k < 4; ++k)
+            if (i0 + k < HW) out[base + i0 + k] = raw[base + i0 + k] / den;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------
+constexpr int RED_PX = NT * 4;   // pixels summed by one workgroup of the first-level reduction
+
+__device__ __forceinline__ float block_sum(float v, float* s_red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = s_red[0];
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) t += s_red[i];
+    return t;
+}
+
+__global__ __launch_bounds__(NT) void code_pattern_bwd_reduce_kernel(
+    const float* __restrict__ g, const float* __restrict__ out, long HW, float* __restrict__ partial) {
+    __shared__ float s_red[NT / 64];
+    const int b = blockIdx.y;
+    const long base = (long)b * HW;
+    const long i0 = ((long)blockIdx.x * NT + threadIdx.x) * 4;
+    float s = 0.0f;
+    for (int k = 0; k < 4; ++k)
+        if (i0 + k < HW) s = fmaf(g[base + i0 + k], out[base + i0 + k], s);
+    s = block_sum(s, s_red);
+    if (threadIdx.x == 0) partial[(long)b * gridDim.x + blockIdx.x] = s;
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(NT) void code_pattern_bwd_kernel(
+    const float* __restrict__ g, const uint8_t* __restrict__ layer_u8, const float* __restrict__ max_in,
+    const int* __restrict__ argmax_in, const float* __restrict__ partial, int npartial,
+    const float* __restrict__ psf, int H, int W, int L, int Kh, int Kw, int conv, int cap_layers,
+    float* __restrict__ g_pat0) {
+    extern __shared__ float smem[];
+    __shared__ int s_lmin, s_lmax;
+    __shared__ float s_red[NT / 64];
+
+    const int b = blockIdx.z;
+    const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int x = x0 + 4 * tx, y = y0 + ty;
+    const long img = (long)b * H * W;
+    const int KK = Kh * Kw;
+
+    // sum(g*out) over the image: fixed strided order + fixed tree => reproducible
+    float s = 0.0f;
+    for (int i = tid; i < npartial; i += NT) s += partial[(long)b * npartial + i];
+    const float S = block_sum(s, s_red);
+    const float den = max_in[b] + 1e-10f;
+    const float corr = S / den;       // d/d(max) of sum(g * raw/den) = -sum(g*out)/den
+    const int am = argmax_in[b];
+
+    auto graw = [&](int gy, int gx) -> float {
+        const long p = (long)gy * W + gx;
+        const uint8_t l = layer_u8[img + p];
+        if (l == 255) return 0.0f;
+        float v = g[img + p] / den;
+        if ((int)p == am) v -= corr;
+        return v;
+    };
+
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!conv) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (y < H && x + i < W) acc[i] = graw(y, x + i);
+    } else {
+        const TileGeom tg = tile_geom(Kh, Kw);
+        float* tile = smem;                                   // graw with halo
+        float* wts = smem + tg.th * tg.S;                     // PSFs of the staged layer range
+        uint8_t* ltile = reinterpret_cast<uint8_t*>(wts + (long)cap_layers * KK);
+        const int padh = (Kh - 1) / 2, padw = (Kw - 1) / 2;
+        const int hb = Kh - 1 - padh, wb = Kw - 1 - padw;     // halo before the tile (rows / columns)
+        int lmin = 1 << 30, lmax = -1;
+        for (int r = tid / 64; r < tg.th; r += NT / 64) {
+            const int gy = y0 - hb + r;
+            const bool rowok = (gy >= 0) && (gy < H);
+            for (int c = tid & 63; c < tg.S; c += 64) {
+                const int gx = x0 - wb + c;
+                float v = 0.0f;
+                uint8_t l = 255;
+                if (rowok && c < tg.tw && gx >= 0 && gx < W) {
+                    l = layer_u8[img + (long)gy * W + gx];
+                    v = graw(gy, gx);
+                    if (l != 255) {
+                        lmin = min(lmin, (int)l);
+                        lmax = max(lmax, (int)l);
+                    }
+                }
+                tile[r * tg.S + c] = v;
+                ltile[r * tg.S + c] = l;
+            }
+        }
+        block_minmax(lmin, lmax, &s_lmin, &s_lmax);
+        const int bl0 = s_lmin;
+        const int nl = (s_lmax >= bl0) ? min(s_lmax - bl0 + 1, cap_layers) : 0;
+        const float* wsrc = psf + (long)bl0 * KK;
+        for (int i = tid; i < nl * KK; i += NT) wts[i] = wsrc[i];
+        __syncthreads();
+
+        // g_pat0[q] = sum_d PSF[layer(p)][d] * graw[p],  p = q - d + pad.
+        // Staged row of p: ty + (Kh-1-dy); staged column: 4*tx + i + (Kw-1-dx).
+        for (int dy = 0; dy < Kh; ++dy) {
+            const int r = ty + (Kh - 1 - dy);
+            const float* trow = tile + r * tg.S + 4 * tx;
+            const uint8_t* lrow = ltile + r * tg.S + 4 * tx;
+            for (int e = 0; e < Kw + 3; ++e) {
+                const float gv = trow[e];
+                const int l = lrow[e];
+                if (l == 255) continue;
+                const float* wl = (l - bl0 < nl) ? (wts + (l - bl0) * KK) : (psf + (long)l * KK);
+                wl += dy * Kw;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int ee = e - i;
+                    if (ee >= 0 && ee < Kw) acc[i] = fmaf(wl[Kw - 1 - ee], gv, acc[i]);
+                }
+            }
+        }
+    }
+    if (VEC) {
+        if (y < H && x < W)
+            *reinterpret_cast<float4*>(g_pat0 + img + (long)y * W + x) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (y < H && x + i < W) g_pat0[img + (long)y * W + x + i] = acc[i];
+    }
+}
+
+static int layer_capacity(int Kh, int Kw, int L, bool with_layer_tile, size_t* lds_bytes) {
+    const TileGeom tg = tile_geom(Kh, Kw);
+    const size_t tile_b = (size_t)tg.th * tg.S * (with_layer_tile ? 5 : 4);
+    const size_t per_layer = (size_t)Kh * Kw * 4;
+    if (tile_b + per_layer + 16 > (size_t)kLdsBudget) return -1;
+    long cap = (long)((kLdsBudget - tile_b - 16) / per_layer);
+    if (cap > L) cap = L;
+    *lds_bytes = tile_b + (size_t)cap * per_layer + 16;
+    return (int)cap;
+}
+
+}  // namespace fc3d
+
+using namespace fc3d;
+
+extern "C" size_t fc3d_code_pattern_fwd_workspace(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)B * cdiv(W, TX) * cdiv(H, TY) * sizeof(unsigned long long);
+}
+
+extern "C" size_t fc3d_code_pattern_bwd_workspace(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)B * cdiv((long)H * W, RED_PX) * sizeof(float);
+}
+
+extern "C" int fc3d_code_pattern_fwd(void* stream, const float* pat0, int64_t pat_sb, int64_t pat_sh,
+                                     int64_t pat_sw, const float* z, const float* psf, int B, int H, int W,
+                                     int Kh, int Kw, int conv_flag, fc3d_layer_grid grid, float* raw_out,
+                                     uint8_t* layer_u8, uint64_t* tilekey_u64) {
+    if (!pat0 || !z || !raw_out || !tilekey_u64 || B <= 0 || H <= 0 || W <= 0) return FC3D_EINVAL;
+    if (grid.n_layers <= 0 || grid.n_layers > 254) return FC3D_EINVAL;
+    if ((long)B * H * W >= (1L << 31) || B > 65535) return FC3D_ERANGE;
+    if (!aligned4(pat0) || !aligned4(z) || !aligned4(raw_out)) return FC3D_EALIGN;
+    size_t lds = 0;
+    int cap = 0;
+    if (conv_flag) {
+        if (!psf || Kh <= 0 || Kw <= 0) return FC3D_EINVAL;
+        cap = layer_capacity(Kh, Kw, grid.n_layers, false, &lds);
+        if (cap < 1) return FC3D_ERANGE;   // kernel too large for the LDS tile
+    }
+    const bool vec = (W % 4 == 0) && aligned16(z) && aligned16(raw_out) &&
+                     (!layer_u8 || aligned4(layer_u8));
+    dim3 g(cdiv(W, TX), cdiv(H, TY), B), blk(NT);
+    hipStream_t s = (hipStream_t)stream;
+    auto k = vec ? code_pattern_fwd_kernel<true> : code_pattern_fwd_kernel<false>;
+    hipLaunchKernelGGL(k, g, blk, lds, s, pat0, (long)pat_sb, (long)pat_sh, (long)pat_sw, z, psf, H, W, Kh, Kw,
+                       conv_flag, cap, grid, raw_out, layer_u8, (unsigned long long*)tilekey_u64);
+    FC3D_LAUNCH_CHECK();
+    return FC3D_OK;
+}
+
+extern "C" int fc3d_code_pattern_norm(void* stream, const float* raw, const uint64_t* tilekey_u64, int B, int H,
+                                      int W, float* out, float* max_out, int32_t* argmax_i32) {
+    if (!raw || !tilekey_u64 || !out || !max_out || !argmax_i32 || B <= 0 || H <= 0 || W <= 0) return FC3D_EINVAL;
+    if ((long)B * H * W >= (1L << 31) || B > 65535) return FC3D_ERANGE;
+    const int ntiles = cdiv(W, TX) * cdiv(H, TY);
+    const bool vec = (((long)H * W) % 4 == 0) && aligned16(raw) && aligned16(out);
+    dim3 g(cdiv((long)H * W, NT * 4), B), blk(NT);
+    auto k = vec ? code_pattern_norm_kernel<true> : code_pattern_norm_kernel<false>;
+    hipLaunchKernelGGL(k, g, blk, 0, (hipStream_t)stream, raw, (const unsigned long long*)tilekey_u64, ntiles, H, W,
+                       out, max_out, argmax_i32);
+    FC3D_LAUNCH_CHECK();
+    return FC3D_OK;
+}
+
+extern "C" int fc3d_code_pattern_bwd(void* stream, const float* g_out, const float* out, const uint8_t* layer_u8,
+                                     const float* max_in, const int32_t* argmax_i32, const float* psf, int B, int H,
+                                     int W, int L, int Kh, int Kw, int conv_flag, void* workspace, float* g_pat0) {
+    if (!g_out || !out || !layer_u8 || !max_in || !argmax_i32 || !workspace || !g_pat0) return FC3D_EINVAL;
+    if (B <= 0 || H <= 0 || W <= 0 || L <= 0 || L > 254) return FC3D_EINVAL;
+    if ((long)B * H * W >= (1L << 31) || B > 65535) return FC3D_ERANGE;
+    size_t lds = 0;
+    int cap = 0;
+    if (conv_flag) {
+        if (!psf || Kh <= 0 || Kw <= 0) return FC3D_EINVAL;
+        cap = layer_capacity(Kh, Kw, L, true, &lds);
+        if (cap < 1) return FC3D_ERANGE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const long HW = (long)H * W;
+    const int nred = cdiv(HW, RED_PX);
+    float* partial = (float*)workspace;
+    hipLaunchKernelGGL(code_pattern_bwd_reduce_kernel, dim3(nred, B), dim3(NT), 0, s, g_out, out, HW, partial);
+    FC3D_LAUNCH_CHECK();
+    const bool vec = (W % 4 == 0) && aligned16(g_pat0);
+    auto k = vec ? code_pattern_bwd_kernel<true> : code_pattern_bwd_kernel<false>;
+    hipLaunchKernelGGL(k, dim3(cdiv(W, TX), cdiv(H, TY), B), dim3(NT), lds, s, g_out, layer_u8, max_in, argmax_i32,
+                       (const float*)partial, nred, psf, H, W, L, Kh, Kw, conv_flag, cap, g_pat0);
+    FC3D_LAUNCH_CHECK();
+    return FC3D_OK;
+}

@@ -1,0 +1,353 @@
+"""torch.autograd wrappers around the C ABI of libfc3d_hip.so.
+
+PyTorch is used here for device memory, streams and the autograd tape only;
+all arithmetic happens in the HIP kernels.  Tensors must live on a GPU: there
+is deliberately no CPU path.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _native
+from ._native import LayerGrid
+
+_lib = _native.load()
+_check = _native.check
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_gpu(*tensors):
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("fc3d operators run on the GPU only (got a tensor on %s); "
+                               "there is no CPU implementation" % t.device)
+        if t.dtype != torch.float32:
+            raise TypeError(f"fc3d operators are fp32 only (got {t.dtype})")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"tensors on different devices: {dev} and {t.device}")
+    return dev
+
+
+def _dense(t: torch.Tensor) -> torch.Tensor:
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# --------------------------------------------------------------------------- #
+# optics
+# --------------------------------------------------------------------------- #
+def layer_grid(n_layers: int, wvl: float, D: float, z0: float, z_min: float, z_max: float) -> LayerGrid:
+    """The four fp32 scalars of the depth->layer decision, derived in float64 the
+    way optics_pytorch.py:66-67, 82-84 and 40-44 derive them."""
+    coeff = 2 * np.pi / wvl * (D / 2) ** 2 / 2
+    lo = coeff * (1 / z_max - 1 / z0)
+    hi = coeff * (1 / z_min - 1 / z0)
+    layers = np.linspace(lo, hi, n_layers)
+    step = (layers[-1] - layers[0]) / (n_layers - 1) if n_layers > 1 else float("nan")
+    centres = (layers / step).astype(np.float32)
+    c0 = np.float32(centres[0])
+    # The kernel reconstructs centre l as centre0 + l.  r is integer-valued, so the reference's
+    # test |r - centre_l| < 0.01 is the same decision as long as the two differ by far less
+    # than 0.01 (linspace makes them differ by rounding noise only, e.g. 1e-9 at the centre).
+    if n_layers > 1 and not np.all(np.abs(centres.astype(np.float64) - (float(c0) + np.arange(n_layers))) < 1e-4):
+        raise NotImplementedError("layer centres are not one step apart; unsupported optical constants")
+    return LayerGrid(np.float32(coeff), np.float32(1 / z0), np.float32(step), c0, n_layers)
+
+
+class CodePatternFn(torch.autograd.Function):
+    """codePattern on channel 0 of the pattern; optics_pytorch.py:71-121."""
+
+    @staticmethod
+    def forward(ctx, pat0, zMap, psf, grid: LayerGrid, conv: bool):
+        # pat0: [B,H,W,1] (any strides), zMap: [B,H,W,1], psf: [L,Kh,Kw] dense on the device
+        dev = _need_gpu(pat0, zMap, psf)
+        B, H, W, _ = pat0.shape
+        if tuple(zMap.shape) != (B, H, W, 1):
+            raise RuntimeError(f"zMap shape {tuple(zMap.shape)} does not match pattern {tuple(pat0.shape)}")
+        z = _dense(zMap)
+        L = grid.n_layers
+        Kh, Kw = (int(psf.shape[1]), int(psf.shape[2])) if conv else (1, 1)
+        out = torch.empty((B, H, W, 1), dtype=torch.float32, device=dev)
+        layer = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+        keys = torch.empty(_lib.fc3d_code_pattern_fwd_workspace(B, H, W) // 8, dtype=torch.int64, device=dev)
+        mx = torch.empty(B, dtype=torch.float32, device=dev)
+        am = torch.empty(B, dtype=torch.int32, device=dev)
+        s = _stream()
+        with torch.cuda.device(dev):
+            _check(_lib.fc3d_code_pattern_fwd(s, pat0.data_ptr(), pat0.stride(0), pat0.stride(1), pat0.stride(2),
+                                              z.data_ptr(), psf.data_ptr() if conv else None, B, H, W, Kh, Kw,
+                                              int(conv), grid, out.data_ptr(), layer.data_ptr(), keys.data_ptr()),
+                   "fc3d_code_pattern_fwd")
+            _check(_lib.fc3d_code_pattern_norm(s, out.data_ptr(), keys.data_ptr(), B, H, W, out.data_ptr(),
+                                               mx.data_ptr(), am.data_ptr()), "fc3d_code_pattern_norm")
+        ctx.save_for_backward(out, layer, mx, am, psf)
+        ctx.meta = (B, H, W, L, Kh, Kw, conv)
+        ctx.mark_non_differentiable(layer, mx, am)
+        return out, layer, mx, am
+
+    @staticmethod
+    def backward(ctx, g_out, _gl, _gm, _ga):
+        out, layer, mx, am, psf = ctx.saved_tensors
+        B, H, W, L, Kh, Kw, conv = ctx.meta
+        g = _dense(g_out)
+        dev = g.device
+        ws = torch.empty(max(1, _lib.fc3d_code_pattern_bwd_workspace(B, H, W) // 4), dtype=torch.float32, device=dev)
+        gp = torch.empty((B, H, W, 1), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _check(_lib.fc3d_code_pattern_bwd(_stream(), g.data_ptr(), out.data_ptr(), layer.data_ptr(),
+                                              mx.data_ptr(), am.data_ptr(), psf.data_ptr() if conv else None,
+                                              B, H, W, L, Kh, Kw, int(conv), ws.data_ptr(), gp.data_ptr()),
+                   "fc3d_code_pattern_bwd")
+        return gp, None, None, None, None
+
+
+# --------------------------------------------------------------------------- #
+# geometry
+# --------------------------------------------------------------------------- #
+def pose_transforms(pose: torch.Tensor, K: torch.Tensor | None, want_fwd=False, want_inv=False, want_a=False):
+    """(K@pose, K@inv(pose), inv(pose)) as [B,4,4] tensors (None where not asked for)."""
+    dev = _need_gpu(pose, K)
+    if pose.dim() != 3 or tuple(pose.shape[1:]) != (4, 4):
+        raise RuntimeError(f"pose must be [B,4,4], got {tuple(pose.shape)}")
+    B = pose.shape[0]
+    p = _dense(pose)
+    k_ptr, k_sb = None, 0
+    if K is not None:
+        K = _dense(K)
+        if K.dim() == 3:
+            if K.shape[0] not in (1, B) or tuple(K.shape[1:]) != (4, 4):
+                raise RuntimeError(f"intrinsics must be [B,4,4], got {tuple(K.shape)}")
+            k_sb = 16 if K.shape[0] == B and B > 1 else 0
+        elif tuple(K.shape) != (4, 4):
+            raise RuntimeError(f"intrinsics must be [4,4] or [B,4,4], got {tuple(K.shape)}")
+        k_ptr = K.data_ptr()
+    tf = torch.empty((B, 4, 4), dtype=torch.float32, device=dev) if want_fwd else None
+    ti = torch.empty((B, 4, 4), dtype=torch.float32, device=dev) if want_inv else None
+    a = torch.empty((B, 4, 4), dtype=torch.float32, device=dev) if want_a else None
+    with torch.cuda.device(dev):
+        _check(_lib.fc3d_pose_transforms(_stream(), p.data_ptr(), k_ptr, k_sb, B,
+                                         tf.data_ptr() if want_fwd else None, ti.data_ptr() if want_inv else None,
+                                         a.data_ptr() if want_a else None), "fc3d_pose_transforms")
+    return tf, ti, a
+
+
+def _coord_args(coord: torch.Tensor):
+    """Pointer + element strides of a [B,4,H,W] coordinate tensor; broadcast (stride-0)
+    or otherwise exotic views are densified first."""
+    if coord.dim() != 4 or coord.shape[1] != 4:
+        raise RuntimeError(f"coord must be [B,4,H,W], got {tuple(coord.shape)}")
+    st = coord.stride()
+    if min(st) <= 0 and coord.numel() > 0:
+        coord = coord.contiguous()
+        st = coord.stride()
+    return coord, st
+
+
+class ProjectFn(torch.autograd.Function):
+    """coord_transform; geometry_pytorch.py:68-90."""
+
+    @staticmethod
+    def forward(ctx, coord, T):
+        dev = _need_gpu(coord, T)
+        coord, st = _coord_args(coord)
+        B, _, H, W = coord.shape
+        if tuple(T.shape) != (B, 4, 4):
+            raise RuntimeError(f"transform must be [{B},4,4], got {tuple(T.shape)}")
+        T = _dense(T)
+        grid = torch.empty((B, H, W, 2), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _check(_lib.fc3d_project_fwd(_stream(), coord.data_ptr(), st[0], st[1], st[2], st[3], T.data_ptr(),
+                                         B, H, W, grid.data_ptr()), "fc3d_project_fwd")
+        ctx.save_for_backward(coord, T)
+        return grid
+
+    @staticmethod
+    def backward(ctx, g_grid):
+        coord, T = ctx.saved_tensors
+        if ctx.needs_input_grad[1]:
+            raise NotImplementedError("gradient w.r.t. the pose/transform of coord_transform is not implemented")
+        B, _, H, W = coord.shape
+        g = _dense(g_grid)
+        st = coord.stride()
+        gc = torch.empty((B, 4, H, W), dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            _check(_lib.fc3d_project_bwd(_stream(), g.data_ptr(), coord.data_ptr(), st[0], st[1], st[2], st[3],
+                                         T.data_ptr(), B, H, W, gc.data_ptr()), "fc3d_project_bwd")
+        return gc, None
+
+
+def _bilinear_bwd_img(g, grid, mask, B, Hs, Ws, C, Ht, Wt):
+    dev = g.device
+    nbytes = _lib.fc3d_bilinear_bwd_img_workspace(B, Hs, Ws, C, Ht, Wt)
+    ws = torch.empty(max(16, nbytes) // 4, dtype=torch.float32, device=dev)
+    gi = torch.empty((B, Hs, Ws, C), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _check(_lib.fc3d_bilinear_bwd_img(_stream(), g.data_ptr(), grid.data_ptr(),
+                                          mask.data_ptr() if mask is not None else None, B, Hs, Ws, C, Ht, Wt,
+                                          ws.data_ptr(), gi.data_ptr()), "fc3d_bilinear_bwd_img")
+    return gi
+
+
+class BilinearFn(torch.autograd.Function):
+    """bilinear_sampler; geometry_pytorch.py:109-177."""
+
+    @staticmethod
+    def forward(ctx, imgs, coords):
+        dev = _need_gpu(imgs, coords)
+        if imgs.dim() != 4 or coords.dim() != 4 or coords.shape[-1] != 2 or coords.shape[0] != imgs.shape[0]:
+            raise RuntimeError(f"bilinear_sampler: imgs {tuple(imgs.shape)} / coords {tuple(coords.shape)}")
+        img, grid = _dense(imgs), _dense(coords)
+        B, Hs, Ws, C = img.shape
+        _, Ht, Wt, _ = grid.shape
+        out = torch.empty((B, Ht, Wt, C), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _check(_lib.fc3d_bilinear_fwd(_stream(), img.data_ptr(), grid.data_ptr(), None, B, Hs, Ws, C, Ht, Wt,
+                                          out.data_ptr()), "fc3d_bilinear_fwd")
+        ctx.save_for_backward(img, grid)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        img, grid = ctx.saved_tensors
+        B, Hs, Ws, C = img.shape
+        _, Ht, Wt, _ = grid.shape
+        g = _dense(g_out)
+        gi = gg = None
+        if ctx.needs_input_grad[0]:
+            gi = _bilinear_bwd_img(g, grid, None, B, Hs, Ws, C, Ht, Wt)
+        if ctx.needs_input_grad[1]:
+            gg = torch.empty_like(grid)
+            with torch.cuda.device(g.device):
+                _check(_lib.fc3d_bilinear_bwd_grid(_stream(), g.data_ptr(), img.data_ptr(), grid.data_ptr(), None,
+                                                   B, Hs, Ws, C, Ht, Wt, gg.data_ptr()), "fc3d_bilinear_bwd_grid")
+        return gi, gg
+
+
+def visible_mask(grid: torch.Tensor, method: int) -> torch.Tensor:
+    """gen_visible_mask as a float [B,H,W,1] tensor; geometry_pytorch.py:180-222."""
+    dev = _need_gpu(grid)
+    if grid.dim() != 4 or grid.shape[-1] != 2:
+        raise RuntimeError(f"grid must be [B,H,W,2], got {tuple(grid.shape)}")
+    g = _dense(grid.detach())
+    B, H, W, _ = g.shape
+    out = torch.empty((B, H, W, 1), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _check(_lib.fc3d_visible_mask(_stream(), g.data_ptr(), B, H, W, method, out.data_ptr(), None),
+               "fc3d_visible_mask")
+    return out
+
+
+class WarpP2CFn(torch.autograd.Function):
+    """warp_p2c with gradient w.r.t. Ip only (coords and pose are data);
+    geometry_pytorch.py:255-281."""
+
+    @staticmethod
+    def forward(ctx, Ip, coord_p, coord_c, T_p2c, T_c2p):
+        dev = _need_gpu(Ip, coord_p, coord_c, T_p2c, T_c2p)
+        coord_p, sp = _coord_args(coord_p)
+        coord_c, sc = _coord_args(coord_c)
+        B, _, H, W = coord_p.shape
+        if tuple(coord_c.shape) != (B, 4, H, W) or tuple(Ip.shape) != (B, H, W, 1):
+            raise RuntimeError(f"warp_p2c: Ip {tuple(Ip.shape)}, coord_p {tuple(coord_p.shape)}, "
+                               f"coord_c {tuple(coord_c.shape)}")
+        ip = _dense(Ip)
+        Ic = torch.empty((B, H, W, 1), dtype=torch.float32, device=dev)
+        gp2c = torch.empty((B, H, W, 2), dtype=torch.float32, device=dev)
+        gc2p = torch.empty((B, H, W, 2), dtype=torch.float32, device=dev)
+        mask = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _check(_lib.fc3d_warp_p2c_fwd(_stream(), ip.data_ptr(), coord_p.data_ptr(), sp[0], sp[1], sp[2], sp[3],
+                                          coord_c.data_ptr(), sc[0], sc[1], sc[2], sc[3], T_p2c.data_ptr(),
+                                          T_c2p.data_ptr(), B, H, W, Ic.data_ptr(), gp2c.data_ptr(), gc2p.data_ptr(),
+                                          mask.data_ptr()), "fc3d_warp_p2c_fwd")
+        ctx.save_for_backward(gc2p, mask)
+        ctx.mark_non_differentiable(gp2c, gc2p, mask)
+        return Ic, gp2c, gc2p, mask
+
+    @staticmethod
+    def backward(ctx, g_Ic, _g1, _g2, _g3):
+        gc2p, mask = ctx.saved_tensors
+        B, H, W, _ = gc2p.shape
+        gi = _bilinear_bwd_img(_dense(g_Ic), gc2p, mask, B, H, W, 1, H, W)
+        return gi, None, None, None, None
+
+
+class PointsFn(torch.autograd.Function):
+    """points_in_camera_coords; geometry_pytorch.py:44-65.  Returns [B,H,W,4]."""
+
+    @staticmethod
+    def forward(ctx, z_map, ray_x, ray_y, ray_dense):
+        dev = _need_gpu(z_map, ray_x, ray_y, ray_dense)
+        if z_map.dim() != 4 or z_map.shape[-1] != 1:
+            raise RuntimeError(f"z_map must be [B,H,W,1], got {tuple(z_map.shape)}")
+        z = _dense(z_map)
+        B, H, W, _ = z.shape
+        sb = 0
+        if ray_dense is not None:
+            ray_dense = _dense(ray_dense)
+            if tuple(ray_dense.shape[-3:]) != (H, W, 3):
+                raise RuntimeError(f"The size of tensor a ({W}) must match the size of tensor b "
+                                   f"({ray_dense.shape[-2]}) at non-singleton dimension 2")
+            sb = H * W * 3 if (ray_dense.dim() == 4 and ray_dense.shape[0] == B and B > 1) else 0
+        elif ray_x.numel() != W or ray_y.numel() != H:
+            raise RuntimeError(f"The size of tensor a ({W}) must match the size of tensor b ({ray_x.numel()}) "
+                               "at non-singleton dimension 2")
+        out = torch.empty((B, H, W, 4), dtype=torch.float32, device=dev)
+        ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+        with torch.cuda.device(dev):
+            _check(_lib.fc3d_points_fwd(_stream(), z.data_ptr(), ptr(ray_x), ptr(ray_y), ptr(ray_dense), sb, B, H, W,
+                                        out.data_ptr()), "fc3d_points_fwd")
+        ctx.rays = (ray_x, ray_y, ray_dense, sb)
+        ctx.shape = (B, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        ray_x, ray_y, ray_dense, sb = ctx.rays
+        B, H, W = ctx.shape
+        g = _dense(g_out)
+        gz = torch.empty((B, H, W, 1), dtype=torch.float32, device=g.device)
+        ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+        with torch.cuda.device(g.device):
+            _check(_lib.fc3d_points_bwd(_stream(), g.data_ptr(), ptr(ray_x), ptr(ray_y), ptr(ray_dense), sb, B, H, W,
+                                        gz.data_ptr()), "fc3d_points_bwd")
+        return gz, None, None, None
+
+
+class ZpToZcFn(torch.autograd.Function):
+    """zp_cView_to_zc given inverse(pose); geometry_pytorch.py:284-308."""
+
+    @staticmethod
+    def forward(ctx, zp, xy, inv):
+        dev = _need_gpu(zp, xy, inv)
+        B, H, W, _ = zp.shape
+        if tuple(xy.shape) != (B, H, W, 2) or tuple(inv.shape) != (B, 4, 4):
+            raise RuntimeError(f"zp_cView_to_zc: zp {tuple(zp.shape)}, xy {tuple(xy.shape)}, pose {tuple(inv.shape)}")
+        z, r = _dense(zp), _dense(xy)
+        out = torch.empty_like(z)
+        with torch.cuda.device(dev):
+            _check(_lib.fc3d_zp_to_zc_fwd(_stream(), z.data_ptr(), r.data_ptr(), inv.data_ptr(), B, H, W,
+                                          out.data_ptr()), "fc3d_zp_to_zc_fwd")
+        ctx.save_for_backward(r, inv)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        r, inv = ctx.saved_tensors
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            raise NotImplementedError("zp_cView_to_zc: only the gradient w.r.t. zp_cView is implemented")
+        B, H, W, _ = r.shape
+        g = _dense(g)
+        gz = torch.empty_like(g)
+        with torch.cuda.device(g.device):
+            _check(_lib.fc3d_zp_to_zc_bwd(_stream(), g.data_ptr(), r.data_ptr(), inv.data_ptr(), B, H, W,
+                                          gz.data_ptr()), "fc3d_zp_to_zc_bwd")
+        return gz, None, None

@@ -1,0 +1,172 @@
+/* fc3d.h -- C ABI of libfc3d_hip.so: MI355X (gfx950) kernels for the FreeCam3D
+ * image-formation path (depth-layered PSF blur; pose reprojection, bilinear
+ * warp, forward-splat visibility and compositing), forward and backward.
+ *
+ * The reference reaches this path through plain Python functions on torch
+ * tensors (it has no FFI).  Each entry point below names the reference function
+ * whose tensor arithmetic it replaces; paths are relative to the reference
+ * checkout.  The Python modules optics_pytorch.py / geometry_pytorch.py of this
+ * project keep the reference's names and signatures and call these symbols
+ * through ctypes with raw device pointers.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless the comment says "host";
+ *  - all tensors are fp32 unless the name ends in _u8 / _i32 / _u64;
+ *  - images are dense row-major [B][H][W][C]; where an input may be a strided
+ *    view the element strides are passed explicitly;
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *    every call only enqueues work and returns, nothing synchronises, nothing
+ *    allocates: the caller owns outputs and workspaces;
+ *  - return value: 0 ok, <0 invalid argument (FC3D_E*), >0 a hipError_t raised
+ *    by a launch.  fc3d_status_string() explains either.
+ */
+#ifndef FC3D_H
+#define FC3D_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FC3D_OK 0
+#define FC3D_EINVAL (-1)     /* null pointer / non-positive size */
+#define FC3D_ERANGE (-2)     /* size beyond what the kernels index (e.g. B*H*W >= 2^31) */
+#define FC3D_EALIGN (-3)     /* pointer not aligned to its element type */
+
+#define FC3D_VERSION 100
+
+int fc3d_version(void);
+const char *fc3d_status_string(int status);
+
+/* ------------------------------------------------------------------------ */
+/* optics: codePattern, optics_pytorch.py:71-121 (with z2Wm :58-68 and the     */
+/* one-hot layer mask gen_WmMask :30-55 evaluated per pixel on the fly)        */
+/* ------------------------------------------------------------------------ */
+
+/* Depth -> layer decision, all in fp32 like the reference's tensor ops:
+ *   Wm = coeff * (1/z - inv_z0);  r = rint(Wm / step);  l = rint(r - centre0);
+ *   valid iff 0 <= l < L and |r - (centre0 + l)| < 0.01.
+ * The caller computes the four scalars in float64 exactly as the reference's
+ * Python does (np.linspace of the layer centres) and casts them to fp32.      */
+typedef struct fc3d_layer_grid {
+    float coeff;     /* k*(D/2)^2/2 cast to fp32      (optics_pytorch.py:66-67) */
+    float inv_z0;    /* 1/z0                          (optics_pytorch.py:67)    */
+    float step;      /* layer spacing in Wm, fp32     (optics_pytorch.py:41)    */
+    float centre0;   /* Wm_layers[0]/step, fp32       (optics_pytorch.py:44)    */
+    int32_t n_layers;
+} fc3d_layer_grid;
+
+/* Bytes of the tile-key buffer shared by fc3d_code_pattern_fwd/_norm, and of the
+ * workspace fc3d_code_pattern_bwd needs (both tiny: one word per 1024 pixels).  */
+size_t fc3d_code_pattern_fwd_workspace(int B, int H, int W);
+size_t fc3d_code_pattern_bwd_workspace(int B, int H, int W);
+
+/* Forward, first half: un-normalised blurred image and the per-image maximum.
+ *   pat0        channel 0 of the pattern as a strided view: element (b,y,x) at
+ *               pat0[b*pat_sb + y*pat_sh + x*pat_sw]   (optics_pytorch.py:97)
+ *   z           [B][H][W] depth
+ *   psf         [L][Kh][Kw] cross-correlation weights (optics_pytorch.py:90,105);
+ *               ignored when conv_flag == 0 (the is_conv_psf=False branch :110-112)
+ *   raw_out     [B][H][W]  sum_l conv_l * mask_l                  (:115)
+ *   layer_u8    [B][H][W]  layer index, 255 = no layer (may be NULL)
+ *   tilekey_u64 fc3d_code_pattern_fwd_workspace() bytes: one packed key per 64x16
+ *               tile (ordered max value | first-w-then-h position priority), fully
+ *               overwritten.  Zero 'same' padding: (K-1)/2 before, the rest after.  */
+int fc3d_code_pattern_fwd(void *stream, const float *pat0, int64_t pat_sb, int64_t pat_sh, int64_t pat_sw,
+                          const float *z, const float *psf, int B, int H, int W, int Kh, int Kw,
+                          int conv_flag, fc3d_layer_grid grid,
+                          float *raw_out, uint8_t *layer_u8, uint64_t *tilekey_u64);
+
+/* Forward, second half: out = raw / (max + 1e-10) per image, in place allowed
+ * (optics_pytorch.py:118-119).  Also unpacks max_out[B] and argmax_i32[B]
+ * (flat y*W+x of the pixel that receives the max's gradient).                 */
+int fc3d_code_pattern_norm(void *stream, const float *raw, const uint64_t *tilekey_u64, int B, int H, int W,
+                           float *out, float *max_out, int32_t *argmax_i32);
+
+/* Backward w.r.t. pattern[...,0] (autograd of optics_pytorch.py:97-119).
+ *   g_out [B][H][W] upstream gradient; out = the normalised forward result.   */
+int fc3d_code_pattern_bwd(void *stream, const float *g_out, const float *out, const uint8_t *layer_u8,
+                          const float *max_in, const int32_t *argmax_i32, const float *psf,
+                          int B, int H, int W, int L, int Kh, int Kw, int conv_flag,
+                          void *workspace, float *g_pat0);
+
+/* ------------------------------------------------------------------------ */
+/* geometry                                                                    */
+/* ------------------------------------------------------------------------ */
+
+/* Per-sample 4x4 products used by coord0TOgrid1 / warp_p2c / zp_cView_to_zc:
+ *   inv_out   [B][16] inverse of pose                      (geometry_pytorch.py:271,294)
+ *   t_fwd_out [B][16] K * pose,  t_inv_out [B][16] K * inverse(pose)   (:103-104)
+ * K is the intrinsic matrix get_intrinsic (:238-252) returns, read from device
+ * memory at K[b*k_sb + 4*i + j] (k_sb = 0 for one matrix shared by the batch).
+ * Any output may be NULL (K may be NULL if only inv_out is wanted).  The inverse
+ * is computed in fp64 and rounded once; the 4x4 products use separately rounded
+ * multiplies and left-to-right adds like torch's small-matrix path.            */
+int fc3d_pose_transforms(void *stream, const float *pose, const float *K, int64_t k_sb, int B,
+                         float *t_fwd_out, float *t_inv_out, float *inv_out);
+
+/* coord_transform, geometry_pytorch.py:68-90: grid[b][y][x] = (xu, yu)/(zu+1e-10),
+ * u = T[b] * coord[b][:, y, x].  coord element (b,c,y,x) at
+ * coord[b*sb + c*sc + y*sh + x*sw] (the reference is handed both planar
+ * [B,4,H,W] tensors and permuted [B,H,W,4] ones, :234).                       */
+int fc3d_project_fwd(void *stream, const float *coord, int64_t sb, int64_t sc, int64_t sh, int64_t sw,
+                     const float *T, int B, int H, int W, float *grid_out);
+
+/* Backward of the above w.r.t. coord: g_coord is dense planar [B][4][H][W].   */
+int fc3d_project_bwd(void *stream, const float *g_grid, const float *coord, int64_t sb, int64_t sc,
+                     int64_t sh, int64_t sw, const float *T, int B, int H, int W, float *g_coord);
+
+/* bilinear_sampler, geometry_pytorch.py:109-177.  img [B][Hs][Ws][C],
+ * grid [B][Ht][Wt][2] -> out [B][Ht][Wt][C].  mask_u8 [B][Ht][Wt] (may be NULL)
+ * multiplies the result (the compositing step of warp_p2c, :279).             */
+int fc3d_bilinear_fwd(void *stream, const float *img, const float *grid, const uint8_t *mask_u8,
+                      int B, int Hs, int Ws, int C, int Ht, int Wt, float *out);
+
+/* d out / d grid: g_grid [B][Ht][Wt][2].                                      */
+int fc3d_bilinear_bwd_grid(void *stream, const float *g_out, const float *img, const float *grid,
+                           const uint8_t *mask_u8, int B, int Hs, int Ws, int C, int Ht, int Wt,
+                           float *g_grid);
+
+/* d out / d img (scatter-add of the four weighted taps), written -- not
+ * accumulated -- to g_img [B][Hs][Ws][C].  C == 1 is deterministic and free of
+ * global atomics (per-wavefront LDS windows merged in a fixed order).         */
+size_t fc3d_bilinear_bwd_img_workspace(int B, int Hs, int Ws, int C, int Ht, int Wt);
+int fc3d_bilinear_bwd_img(void *stream, const float *g_out, const float *grid, const uint8_t *mask_u8,
+                          int B, int Hs, int Ws, int C, int Ht, int Wt, void *workspace, float *g_img);
+
+/* gen_visible_mask, geometry_pytorch.py:180-222.  method 0 = 'all', 1 = 'round'.
+ * Either output may be NULL; both are cleared by the call.                    */
+int fc3d_visible_mask(void *stream, const float *grid, int B, int H, int W, int method,
+                      float *mask_f32, uint8_t *mask_u8);
+
+/* warp_p2c forward, geometry_pytorch.py:255-281, given T_p2c = K*pose and
+ * T_c2p = K*inverse(pose): writes grid_p2c, grid_c2p, the visibility mask and
+ * Ic_masked = sample(Ip, grid_c2p) * mask.                                    */
+int fc3d_warp_p2c_fwd(void *stream, const float *Ip,
+                      const float *coord_p, int64_t p_sb, int64_t p_sc, int64_t p_sh, int64_t p_sw,
+                      const float *coord_c, int64_t c_sb, int64_t c_sc, int64_t c_sh, int64_t c_sw,
+                      const float *T_p2c, const float *T_c2p, int B, int H, int W,
+                      float *Ic_masked, float *grid_p2c, float *grid_c2p, uint8_t *mask_u8);
+
+/* points_in_camera_coords, geometry_pytorch.py:44-65: out [B][H][W][4] =
+ * (z*rx, z*ry, z*rz, 1).  Rays either separable (ray_x[W], ray_y[H], rz = 1:
+ * the table pixel_to_ray_array :30-41 produces) or a dense table with batch
+ * stride ray_sb (0 for a shared [H][W][3] table).                             */
+int fc3d_points_fwd(void *stream, const float *z, const float *ray_x, const float *ray_y,
+                    const float *ray_dense, int64_t ray_sb, int B, int H, int W, float *out);
+int fc3d_points_bwd(void *stream, const float *g_out, const float *ray_x, const float *ray_y,
+                    const float *ray_dense, int64_t ray_sb, int B, int H, int W, float *g_z);
+
+/* zp_cView_to_zc, geometry_pytorch.py:284-308, given inv = inverse(pose) [B][16]:
+ * zc = (zp - a23) / (a20*x + a21*y + a22).  Backward w.r.t. zp.               */
+int fc3d_zp_to_zc_fwd(void *stream, const float *zp, const float *xy, const float *inv, int B, int H, int W,
+                      float *zc);
+int fc3d_zp_to_zc_bwd(void *stream, const float *g_zc, const float *xy, const float *inv, int B, int H, int W,
+                      float *g_zp);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FC3D_H */

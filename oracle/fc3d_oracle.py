@@ -236,9 +236,14 @@ def gen_visible_mask(grid: torch.Tensor, method: str = 'round') -> torch.Tensor:
     return out[:, :H * W].float().reshape(B, H, W, 1)
 
 
-def warp_p2c(Ip, coord_p, coord_c, pose_p2c, cx: float = 600.0, cy: float = 400.0):
-    """geometry_pytorch.py:255-281 -> (Ic*mask, grid_p2c, grid_c2p)."""
-    pose_c2p = torch.linalg.inv(pose_p2c)
+def warp_p2c(Ip, coord_p, coord_c, pose_p2c, cx: float = 600.0, cy: float = 400.0, pose_c2p=None):
+    """geometry_pytorch.py:255-281 -> (Ic*mask, grid_p2c, grid_c2p).
+
+    pose_c2p: optional precomputed inverse.  LAPACK's fp32 inverse differs in the
+    last bit from host to host, so bit-exact comparisons against a fixture pass the
+    inverse that was recorded with it."""
+    if pose_c2p is None:
+        pose_c2p = torch.linalg.inv(pose_p2c)
     grid_c2p = coord0TOgrid1(coord_c, pose_c2p, cx, cy)
     Ic = bilinear_sampler(Ip, grid_c2p)
     grid_p2c = coord0TOgrid1(coord_p, pose_p2c, cx, cy)
@@ -246,9 +251,9 @@ def warp_p2c(Ip, coord_p, coord_c, pose_p2c, cx: float = 600.0, cy: float = 400.
     return Ic * vis, grid_p2c, grid_c2p
 
 
-def zp_cView_to_zc(zp_cView, pose_p2c, xy):
+def zp_cView_to_zc(zp_cView, pose_p2c, xy, pose_c2p=None):
     """geometry_pytorch.py:284-308."""
-    A = torch.linalg.inv(pose_p2c)
+    A = torch.linalg.inv(pose_p2c) if pose_c2p is None else pose_c2p
     a = A[:, 2, :].reshape(-1, 1, 1, 4)
     den = a[..., 0:1] * xy[..., 0:1] + a[..., 1:2] * xy[..., 1:2] + a[..., 2:3]
     return (zp_cView - a[..., 3:4]) / den
@@ -257,19 +262,21 @@ def zp_cView_to_zc(zp_cView, pose_p2c, xy):
 # --------------------------------------------------------------------------- #
 # the two callers of the path, reduced to their tensor math
 # --------------------------------------------------------------------------- #
-def image_formation(pattern, z_p, coord_p, coord_c, pose_p2c, psfs, cx, cy, is_conv_psf=True):
+def image_formation(pattern, z_p, coord_p, coord_c, pose_p2c, psfs, cx, cy, is_conv_psf=True, pose_c2p=None):
     """codePattern -> warp_p2c, the part of forward_model that the captures/s
     metric counts; train_pytorch.py:94-97."""
     Ip_coded = codePattern(pattern, z_p, psfs, is_conv_psf)
-    Ic, grid_p2c, grid_c2p = warp_p2c(Ip_coded, coord_p, coord_c, pose_p2c, cx, cy)
+    Ic, grid_p2c, grid_c2p = warp_p2c(Ip_coded, coord_p, coord_c, pose_p2c, cx, cy, pose_c2p)
     return Ip_coded, Ic, grid_p2c, grid_c2p
 
 
-def reproject_chain(zp_cView, pose_p2c, xy, IpGT, cx, cy):
+def reproject_chain(zp_cView, pose_p2c, xy, IpGT, cx, cy, pose_c2p=None):
     """zp -> zc -> scene points -> projector pixel -> sampled pattern; the
     differentiable part of reProj_IpGT, train_pytorch.py:194-202 (B_sub=1)."""
-    zc = zp_cView_to_zc(zp_cView, pose_p2c, xy)
+    if pose_c2p is None:
+        pose_c2p = torch.linalg.inv(pose_p2c)
+    zc = zp_cView_to_zc(zp_cView, pose_p2c, xy, pose_c2p)
     ray = torch.cat([xy, torch.ones_like(zc)], dim=-1)
     coord_c = points_in_camera_coords(zc, ray, allBatch=True).permute(0, 3, 1, 2)
-    grid_c2p = coord0TOgrid1(coord_c, torch.linalg.inv(pose_p2c), cx, cy)
+    grid_c2p = coord0TOgrid1(coord_c, pose_c2p, cx, cy)
     return zc, grid_c2p, bilinear_sampler(IpGT, grid_c2p)

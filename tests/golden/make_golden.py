@@ -257,7 +257,13 @@ def g6_warp(G):
         mask = G.gen_visible_mask(gp2c, 'all')
     finally:
         G.get_intrinsic = orig
+    # LAPACK's fp32 inverse differs in the last bit between hosts, so the matrices the
+    # reference actually used are part of the fixture
+    pose_t = t(sc["pose_p2c"])
+    pose_c2p = torch.linalg.inv(pose_t)
+    Kp = patched_intrinsic(G, W / 2, H / 2)(B)
     save("g6_warp_small", z_p=sc["z_p"], z_c=sc["z_c"], pose=sc["pose_p2c"], rays=rays, Ip=Ip, g=g,
+         pose_c2p=pose_c2p, T_p2c=torch.matmul(Kp, pose_t), T_c2p=torch.matmul(Kp, pose_c2p),
          Ic=Ic, grid_p2c=gp2c, grid_c2p=gc2p, mask=mask.to(torch.uint8), grad_Ip=ipt.grad,
          cx=np.array(W / 2), cy=np.array(H / 2), seed=np.array(71))
 
@@ -271,7 +277,11 @@ def g6_warp(G):
     Ic, gp2c, gc2p = G.warp_p2c(t(Ip), coord_p, coord_c, t(sc["pose_p2c"]))
     mask = G.gen_visible_mask(gp2c, 'all')
     s = 7
+    pose_t = t(sc["pose_p2c"])
+    pose_c2p = torch.linalg.inv(pose_t)
+    Kn = G.get_intrinsic(B, device='cpu')
     save("g6_warp_native", seed=np.array(73), ip_seed=np.array(74), stride=np.array(s), pose=sc["pose_p2c"],
+         pose_c2p=pose_c2p, T_p2c=torch.matmul(Kn, pose_t), T_c2p=torch.matmul(Kn, pose_c2p),
          Ic_sub=Ic[:, ::s, ::s], grid_p2c_sub=gp2c[:, ::s, ::s], grid_c2p_sub=gc2p[:, ::s, ::s],
          mask_bits=np.packbits(mask.numpy().astype(np.uint8).reshape(-1)),
          Ic_sum=np.array(float(Ic.double().sum())), mask_sum=np.array(float(mask.sum())))
@@ -301,7 +311,7 @@ def g7_reproj(G):
         (Ic * t(g_ic)).sum().add((zc * t(g_zc)).sum()).backward()
     finally:
         G.get_intrinsic = orig
-    save("g7_reproj", zp=zp, xy=xy, pose=sc["pose_p2c"], IpGT=IpGT, zc=zc, coord_c=coord_c, grid=grid, Ic=Ic,
+    save("g7_reproj", zp=zp, xy=xy, pose=sc["pose_p2c"], pose_c2p=torch.linalg.inv(pose), IpGT=IpGT, zc=zc, coord_c=coord_c, grid=grid, Ic=Ic,
          g_ic=g_ic, g_zc=g_zc, grad_zp=zpt.grad, cx=np.array(W / 2), cy=np.array(H / 2))
 
 

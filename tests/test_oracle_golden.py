@@ -140,7 +140,8 @@ def test_warp_small(golden):
     coord_p = orc.points_in_camera_coords(t(g["z_p"]), g["rays"]).permute(0, 3, 1, 2)
     coord_c = orc.points_in_camera_coords(t(g["z_c"]), g["rays"]).permute(0, 3, 1, 2)
     ip = t(g["Ip"]).requires_grad_(True)
-    Ic, gp2c, gc2p = orc.warp_p2c(ip, coord_p, coord_c, t(g["pose"]), float(g["cx"]), float(g["cy"]))
+    Ic, gp2c, gc2p = orc.warp_p2c(ip, coord_p, coord_c, t(g["pose"]), float(g["cx"]), float(g["cy"]),
+                                  pose_c2p=t(g["pose_c2p"]))
     Ic.backward(t(g["g"]))
     assert np.array_equal(gp2c.numpy(), g["grid_p2c"])
     assert np.array_equal(gc2p.numpy(), g["grid_c2p"])
@@ -158,7 +159,7 @@ def test_warp_native(golden):
     coord_p = orc.z2pointcloud(t(sc["z_p"]))
     coord_c = orc.z2pointcloud(t(sc["z_c"]))
     Ip = np.random.RandomState(int(g["ip_seed"])).uniform(0, 1, (1, 800, 1200, 1)).astype(np.float32)
-    Ic, gp2c, gc2p = orc.warp_p2c(t(Ip), coord_p, coord_c, t(sc["pose_p2c"]))
+    Ic, gp2c, gc2p = orc.warp_p2c(t(Ip), coord_p, coord_c, t(sc["pose_p2c"]), pose_c2p=t(g["pose_c2p"]))
     s = int(g["stride"])
     assert np.array_equal(gp2c[:, ::s, ::s].numpy(), g["grid_p2c_sub"])
     assert np.array_equal(gc2p[:, ::s, ::s].numpy(), g["grid_c2p_sub"])
@@ -171,7 +172,8 @@ def test_warp_native(golden):
 def test_reproj_chain(golden):
     g = golden("g7_reproj")
     zp = t(g["zp"]).requires_grad_(True)
-    zc, grid, Ic = orc.reproject_chain(zp, t(g["pose"]), t(g["xy"]), t(g["IpGT"]), float(g["cx"]), float(g["cy"]))
+    zc, grid, Ic = orc.reproject_chain(zp, t(g["pose"]), t(g["xy"]), t(g["IpGT"]), float(g["cx"]), float(g["cy"]),
+                                       pose_c2p=t(g["pose_c2p"]))
     ((Ic * t(g["g_ic"])).sum() + (zc * t(g["g_zc"])).sum()).backward()
     assert np.array_equal(zc.detach().numpy(), g["zc"])
     assert np.array_equal(grid.detach().numpy(), g["grid"])
