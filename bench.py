@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""Simulated captures/s, forward + backward, of the FreeCam3D image-formation path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C2] [--psf-k 5]
+
+One step = one batch of synthetic scenes through
+    codePattern(pattern, z_p)  ->  warp_p2c(Ip_coded, coord_p, coord_c, pose_p2c)
+forward, then backward from a fixed dL/dIc to dL/dpattern[...,0], called through the
+drop-in modules (optics_pytorch / geometry_pytorch) exactly as the reference's
+forward_model calls them (train_pytorch.py:94-97).  All inputs are resident in HBM before
+the timed region.  The batch is sharded over ranks (weak scaling: --gpus N runs N times the
+per-GPU batch, no collective on the data path), launched one process per GPU by
+torch.distributed.run.
+
+Prints ONE json line on rank 0 with the whole-job rate, the roofline fraction of the
+dominant kernel (timed with HIP events on the launching stream) and, at N=1, the CPU
+oracle's rate on the host cores for comparison.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "depth-estimation_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK = 8.0e12   # B/s, MI355X HBM3E nominal
+
+# Algorithmic bytes per pixel charged to each kernel of the path: every consumed input element
+# read once, every returned tensor / gradient written once (fp32).  They add up to the 100 B/px
+# of one capture, forward + backward.
+ALG_BYTES = {
+    "code_pattern_fwd": 12,           # pattern[...,0] 4 + zMap 4 -> Ip_coded 4
+    "code_pattern_norm": 0,           # second pass over Ip_coded: pure overhead
+    "pose_transforms": 0,
+    "warp_project_splat": 24,         # coord_p 16 -> grid_p2c 8 (mask is internal)
+    "warp_sample": 32,                # Ip 4 + coord_c 16 -> Ic 4 + grid_c2p 8
+    "bilinear_bwd_img_scatter": 12,   # dL/dIc 4 + grid_c2p 8
+    "bilinear_bwd_img_merge": 4,      # -> dL/dIp 4
+    "bilinear_bwd_img_overflow": 0,
+    "code_pattern_bwd_reduce": 0,     # second read of dL/dIp and Ip_coded: overhead
+    "code_pattern_bwd": 16,           # dL/dIp 4 + layer(z) 4 + Ip_coded 4 -> dL/dpattern0 4
+}
+assert sum(ALG_BYTES.values()) == 100
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="C2", help="C1, C2 (headline), C4 or C5")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch override")
+    ap.add_argument("--psf-k", type=int, default=None)
+    ap.add_argument("--psf-kind", default="disc")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def build_inputs(args, rank, device):
+    from fc3d import synth
+    import geometry_pytorch as G
+    import optics_pytorch as O
+
+    wl = synth.make_workload(args.workload, B=args.batch, K=args.psf_k, psf_kind=args.psf_kind,
+                             seed_offset=100 * rank)
+    cfg = wl["cfg"]
+    H, W = cfg["H"], cfg["W"]
+    d = lambda a: torch.from_numpy(a).to(device)  # noqa: E731
+    z_p, z_c, pose = d(wl["z_p"]), d(wl["z_c"]), d(wl["pose_p2c"])
+    rays = G.pixel_to_ray_array(W, H)
+    coord_p = G.points_in_camera_coords(z_p, rays).permute(0, 3, 1, 2)
+    coord_c = G.points_in_camera_coords(z_c, rays).permute(0, 3, 1, 2)
+    O.PSFs_np = wl["psfs"]
+    # principal point at the image centre (the reference hard-codes that of its 1200x800 renders)
+    K = np.diag([1666.67, 1666.67, 1, 1])
+    K[0][2], K[1][2] = W / 2, H / 2
+    Kt = torch.from_numpy(K).float().to(device)
+    Kb = {}
+
+    def centred_intrinsic(B, device="cuda"):
+        if B not in Kb:
+            Kb[B] = Kt.unsqueeze(0).repeat(B, 1, 1)
+        return Kb[B]
+    G.get_intrinsic = centred_intrinsic
+    pat = d(wl["pattern"]).requires_grad_(True)
+    g = d(wl["upstream_grad"])
+    return wl, dict(pat=pat, z_p=z_p, coord_p=coord_p, coord_c=coord_c, pose=pose, g=g, L=cfg["L"])
+
+
+def make_step(t):
+    import geometry_pytorch as G
+    import optics_pytorch as O
+
+    def step():
+        t["pat"].grad = None
+        Ip = O.codePattern(t["pat"], t["z_p"], n_layers=t["L"])
+        Ic, _gp2c, _gc2p = G.warp_p2c(Ip, t["coord_p"], t["coord_c"], t["pose"])
+        Ic.backward(t["g"])
+        return Ic
+    return step
+
+
+def cpu_baseline(wl, seconds):
+    """The CPU oracle (a torch-CPU restatement of the reference's ops, checked against
+    fixtures captured from the reference) on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import fc3d_oracle as orc
+    cfg = wl["cfg"]
+    Bs = min(2, cfg["B"])
+    H, W, L = cfg["H"], cfg["W"], cfg["L"]
+    t = torch.from_numpy
+    z_p, z_c, pose = t(wl["z_p"][:Bs]), t(wl["z_c"][:Bs]), t(wl["pose_p2c"][:Bs])
+    cp, cc = orc.z2pointcloud(z_p), orc.z2pointcloud(z_c)
+    g = t(wl["upstream_grad"][:Bs])
+    p0 = t(wl["pattern"][:Bs]).requires_grad_(True)
+
+    def one():
+        p0.grad = None
+        pat = p0.expand(-1, -1, -1, L)           # the reference consumes an L-channel pattern
+        _, Ic, _, _ = orc.image_formation(pat, z_p, cp, cc, pose, wl["psfs"], W / 2, H / 2)
+        Ic.backward(g)
+
+    one()
+    n, t0 = 0, time.perf_counter()
+    best = float("inf")
+    while True:
+        a = time.perf_counter()
+        one()
+        b = time.perf_counter()
+        best = min(best, b - a)
+        n += 1
+        if b - t0 > seconds or n >= 50:
+            break
+    return dict(value=Bs / best, unit="captures/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{n} repeats of batch {Bs} at {H}x{W}, L={L}, K={cfg['K']} (best of {n}); "
+                       f"host cpu_count={os.cpu_count()}")
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
+        sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    from fc3d import profiler
+    wl, tens = build_inputs(args, rank, device)
+    cfg = wl["cfg"]
+    B, H, W = cfg["B"], cfg["H"], cfg["W"]
+    step = make_step(tens)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # same K steps again with an event pair around every kernel launch
+    profiler.enable(True)
+    profiler.report()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    prof = profiler.report()
+    profiler.enable(False)
+
+    if rank == 0:
+        px = B * H * W
+        kern = {k: dict(launches=n, avg_us=1e3 * ms / n, alg_bytes_per_launch=ALG_BYTES.get(k, 0) * px)
+                for k, (n, ms) in prof.items()}
+        dom = max(kern, key=lambda k: kern[k]["avg_us"] * kern[k]["launches"])
+        dk = kern[dom]
+        achieved = dk["alg_bytes_per_launch"] / (dk["avg_us"] * 1e-6)
+        gpu_sum_us = sum(v["avg_us"] * v["launches"] for v in kern.values()) / args.steps
+        value = world * B * args.steps / elapsed
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                with open(tpath) as f:
+                    traffic = json.load(f).get(f"{args.workload}:K{cfg['K']}:B{B}", {}).get(dom)
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "simulated captures/sec fwd+bwd @512x512 at 1/2/4/8 GPUs; % HBM roofline",
+            "value": value, "unit": "captures/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {B}x{H}x{W} per GPU, L={cfg['L']} depth layers, "
+                                   f"{cfg['K']}x{cfg['K']} '{args.psf_kind}' PSFs, pose theta<={cfg['theta_deg']}deg; "
+                                   "codePattern -> warp_p2c fwd + bwd to pattern[...,0]",
+                       "global_batch": world * B, "parallelism": f"batch-sharded x{world}, no collective"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
+                         "kernel_avg_us": dk["avg_us"], "alg_bytes_per_launch": dk["alg_bytes_per_launch"],
+                         "path_alg_bytes_per_capture": 100 * H * W,
+                         "path_frac_per_gpu": (value / world) * 100 * H * W / HBM_PEAK,
+                         "gpu_kernel_us_per_step": gpu_sum_us},
+            "kernels": {k: {"avg_us": round(v["avg_us"], 2), "launches_per_step": v["launches"] / args.steps,
+                            "alg_GBps": round(v["alg_bytes_per_launch"] / (v["avg_us"] * 1e-6) / 1e9, 1)}
+                        for k, v in kern.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb = cpu_baseline(wl, args.cpu_seconds)
+            out["cpu_baseline"] = cb
+            out["gpu_over_cpu"] = value / cb["value"]
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -45,6 +45,8 @@ SIGNATURES = {
     "fc3d_points_bwd": (c_int, [P, P, P, P, P, I64, c_int, c_int, c_int, P]),
     "fc3d_zp_to_zc_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
     "fc3d_zp_to_zc_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
+    "fc3d_profile_enable": (c_int, [c_int]),
+    "fc3d_profile_report": (c_int, [c_char_p, c_size_t]),
 }
 
 _lib = None

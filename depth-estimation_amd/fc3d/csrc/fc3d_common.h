@@ -22,6 +22,20 @@
 
 namespace fc3d {
 
+bool prof_enabled();
+void prof_before(const char* name, hipStream_t s);
+void prof_after(hipStream_t s);
+
+// Launch + (optionally) time one kernel under a stable display name.
+#define FC3D_LAUNCH(NAME, KERNEL, GRID, BLOCK, LDS, STREAM, ...)                        \
+    do {                                                                               \
+        const bool prof__ = ::fc3d::prof_enabled();                                    \
+        if (prof__) ::fc3d::prof_before(NAME, STREAM);                                 \
+        hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, __VA_ARGS__);             \
+        if (prof__) ::fc3d::prof_after(STREAM);                                        \
+        FC3D_LAUNCH_CHECK();                                                           \
+    } while (0)
+
 constexpr int kWave = 64;
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

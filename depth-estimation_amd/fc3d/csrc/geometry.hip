@@ -711,16 +711,16 @@ static int check_img(int B, int H, int W) {
 // 16*H*W >= 400 selects torch's sgemm (fused multiply-add) path for [B,4,4]x[B,4,HW].
 static inline bool use_fma(int H, int W) { return 16L * H * W >= 400; }
 
-#define FC3D_DISPATCH_LAYOUT(KERNEL, layout, fma, ...)                                                     \
+#define FC3D_DISPATCH_LAYOUT(NAME, KERNEL, layout, fma, ...)                                                     \
     do {                                                                                                   \
         if (fma) {                                                                                         \
-            if (layout == kPlanar4) hipLaunchKernelGGL((KERNEL<kPlanar4, true, ##__VA_ARGS__>), g, blk, 0, s, ARGS); \
-            else if (layout == kPixel4) hipLaunchKernelGGL((KERNEL<kPixel4, true, ##__VA_ARGS__>), g, blk, 0, s, ARGS); \
-            else hipLaunchKernelGGL((KERNEL<kGeneric, true, ##__VA_ARGS__>), g, blk, 0, s, ARGS);           \
+            if (layout == kPlanar4) FC3D_LAUNCH(NAME, (KERNEL<kPlanar4, true, ##__VA_ARGS__>), g, blk, 0, s, ARGS); \
+            else if (layout == kPixel4) FC3D_LAUNCH(NAME, (KERNEL<kPixel4, true, ##__VA_ARGS__>), g, blk, 0, s, ARGS); \
+            else FC3D_LAUNCH(NAME, (KERNEL<kGeneric, true, ##__VA_ARGS__>), g, blk, 0, s, ARGS);           \
         } else {                                                                                           \
-            if (layout == kPlanar4) hipLaunchKernelGGL((KERNEL<kPlanar4, false, ##__VA_ARGS__>), g, blk, 0, s, ARGS); \
-            else if (layout == kPixel4) hipLaunchKernelGGL((KERNEL<kPixel4, false, ##__VA_ARGS__>), g, blk, 0, s, ARGS); \
-            else hipLaunchKernelGGL((KERNEL<kGeneric, false, ##__VA_ARGS__>), g, blk, 0, s, ARGS);          \
+            if (layout == kPlanar4) FC3D_LAUNCH(NAME, (KERNEL<kPlanar4, false, ##__VA_ARGS__>), g, blk, 0, s, ARGS); \
+            else if (layout == kPixel4) FC3D_LAUNCH(NAME, (KERNEL<kPixel4, false, ##__VA_ARGS__>), g, blk, 0, s, ARGS); \
+            else FC3D_LAUNCH(NAME, (KERNEL<kGeneric, false, ##__VA_ARGS__>), g, blk, 0, s, ARGS);          \
         }                                                                                                  \
     } while (0)
 
@@ -732,7 +732,7 @@ extern "C" int fc3d_pose_transforms(void* stream, const float* pose, const float
                                     float* t_fwd_out, float* t_inv_out, float* inv_out) {
     if (!pose || B <= 0) return FC3D_EINVAL;
     if (!K && (t_fwd_out || t_inv_out)) return FC3D_EINVAL;
-    hipLaunchKernelGGL(pose_transforms_kernel, dim3(cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, pose, K,
+    FC3D_LAUNCH("pose_transforms", pose_transforms_kernel, dim3(cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, pose, K,
                        (long)k_sb, B, t_fwd_out, t_inv_out, inv_out);
     FC3D_LAUNCH_CHECK();
     return FC3D_OK;
@@ -748,7 +748,7 @@ extern "C" int fc3d_project_fwd(void* stream, const float* coord, int64_t sb, in
     hipStream_t s = (hipStream_t)stream;
     uint8_t* nomask = nullptr;
 #define ARGS coord, (long)sb, (long)sc, (long)sh, (long)sw, T, H, W, grid_out, nomask
-    FC3D_DISPATCH_LAYOUT(project_kernel, layout, fma, false);
+    FC3D_DISPATCH_LAYOUT("project_fwd", project_kernel, layout, fma, false);
 #undef ARGS
     FC3D_LAUNCH_CHECK();
     return FC3D_OK;
@@ -763,7 +763,7 @@ extern "C" int fc3d_project_bwd(void* stream, const float* g_grid, const float* 
     dim3 g(cdiv((long)H * cdiv(W, 4), NT), 1, B), blk(NT);
     hipStream_t s = (hipStream_t)stream;
 #define ARGS g_grid, coord, (long)sb, (long)sc, (long)sh, (long)sw, T, H, W, g_coord
-    FC3D_DISPATCH_LAYOUT(project_bwd_kernel, layout, fma);
+    FC3D_DISPATCH_LAYOUT("project_bwd", project_bwd_kernel, layout, fma);
 #undef ARGS
     FC3D_LAUNCH_CHECK();
     return FC3D_OK;
@@ -777,7 +777,7 @@ extern "C" int fc3d_bilinear_fwd(void* stream, const float* img, const float* gr
     if ((long)B * Hs * Ws * C >= (1L << 31) || (long)B * Ht * Wt * C >= (1L << 31)) return FC3D_ERANGE;
     if (!aligned4(img) || (reinterpret_cast<uintptr_t>(grid) & 7u)) return FC3D_EALIGN;
     const long np = (long)Ht * Wt;
-    hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(cdiv(np, NT), B), dim3(NT), 0, (hipStream_t)stream, img, grid, mask_u8,
+    FC3D_LAUNCH("bilinear_fwd", bilinear_fwd_kernel, dim3(cdiv(np, NT), B), dim3(NT), 0, (hipStream_t)stream, img, grid, mask_u8,
                        Hs, Ws, C, np, out);
     FC3D_LAUNCH_CHECK();
     return FC3D_OK;
@@ -792,7 +792,7 @@ extern "C" int fc3d_bilinear_bwd_grid(void* stream, const float* g_out, const fl
     if ((long)B * Hs * Ws * C >= (1L << 31) || (long)B * Ht * Wt * C >= (1L << 31)) return FC3D_ERANGE;
     if ((reinterpret_cast<uintptr_t>(grid) & 7u) || (reinterpret_cast<uintptr_t>(g_grid) & 7u)) return FC3D_EALIGN;
     const long np = (long)Ht * Wt;
-    hipLaunchKernelGGL(bilinear_bwd_grid_kernel, dim3(cdiv(np, NT), B), dim3(NT), 0, (hipStream_t)stream, g_out, img,
+    FC3D_LAUNCH("bilinear_bwd_grid", bilinear_bwd_grid_kernel, dim3(cdiv(np, NT), B), dim3(NT), 0, (hipStream_t)stream, g_out, img,
                        grid, mask_u8, Hs, Ws, C, np, g_grid);
     FC3D_LAUNCH_CHECK();
     return FC3D_OK;
@@ -821,7 +821,7 @@ extern "C" int fc3d_bilinear_bwd_img(void* stream, const float* g_out, const flo
     if (C != 1) {
         FC3D_HIP(hipMemsetAsync(g_img, 0, (size_t)B * Hs * Ws * C * sizeof(float), s));
         const long np = (long)Ht * Wt;
-        hipLaunchKernelGGL(bilinear_bwd_img_atomic_kernel, dim3(cdiv(np, NT), B), dim3(NT), 0, s, g_out, grid, mask_u8,
+        FC3D_LAUNCH("bilinear_bwd_img_atomic", bilinear_bwd_img_atomic_kernel, dim3(cdiv(np, NT), B), dim3(NT), 0, s, g_out, grid, mask_u8,
                            Hs, Ws, C, np, g_img);
         FC3D_LAUNCH_CHECK();
         return FC3D_OK;
@@ -832,13 +832,13 @@ extern "C" int fc3d_bilinear_bwd_img(void* stream, const float* g_out, const flo
     TileMeta* meta = (TileMeta*)workspace;
     float* slab = (float*)(meta + (size_t)B * ntiles);
     const dim3 gs(cdiv(ntiles, NT / 64), B), blk(NT);
-    hipLaunchKernelGGL(bilinear_bwd_img_scatter_kernel, gs, blk, 0, s, g_out, grid, mask_u8, Hs, Ws, Ht, Wt, tiles_x,
+    FC3D_LAUNCH("bilinear_bwd_img_scatter", bilinear_bwd_img_scatter_kernel, gs, blk, 0, s, g_out, grid, mask_u8, Hs, Ws, Ht, Wt, tiles_x,
                        ntiles, meta, slab);
     FC3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bilinear_bwd_img_merge_kernel, dim3(cdiv(Ws, MT_X), cdiv(Hs, MT_Y), B), blk, 0, s,
+    FC3D_LAUNCH("bilinear_bwd_img_merge", bilinear_bwd_img_merge_kernel, dim3(cdiv(Ws, MT_X), cdiv(Hs, MT_Y), B), blk, 0, s,
                        (const TileMeta*)meta, (const float*)slab, ntiles, Hs, Ws, g_img);
     FC3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bilinear_bwd_img_overflow_kernel, gs, blk, 0, s, g_out, grid, mask_u8, Hs, Ws, Ht, Wt, tiles_x,
+    FC3D_LAUNCH("bilinear_bwd_img_overflow", bilinear_bwd_img_overflow_kernel, gs, blk, 0, s, g_out, grid, mask_u8, Hs, Ws, Ht, Wt, tiles_x,
                        ntiles, (const TileMeta*)meta, g_img);
     FC3D_LAUNCH_CHECK();
     return FC3D_OK;
@@ -854,7 +854,7 @@ extern "C" int fc3d_visible_mask(void* stream, const float* grid, int B, int H, 
     if (mask_f32) FC3D_HIP(hipMemsetAsync(mask_f32, 0, n * sizeof(float), s));
     if (mask_u8) FC3D_HIP(hipMemsetAsync(mask_u8, 0, n, s));
     const long HW = (long)H * W;
-    hipLaunchKernelGGL(visible_mask_kernel, dim3(cdiv(HW, NT), B), dim3(NT), 0, s, grid, H, W, method, mask_f32,
+    FC3D_LAUNCH("visible_mask", visible_mask_kernel, dim3(cdiv(HW, NT), B), dim3(NT), 0, s, grid, H, W, method, mask_f32,
                        mask_u8);
     FC3D_LAUNCH_CHECK();
     return FC3D_OK;
@@ -874,7 +874,7 @@ extern "C" int fc3d_warp_p2c_fwd(void* stream, const float* Ip, const float* coo
     {
         const int layout = pick_layout(coord_p, p_sc, p_sh, p_sw, W, grid_p2c, nullptr);
 #define ARGS coord_p, (long)p_sb, (long)p_sc, (long)p_sh, (long)p_sw, T_p2c, H, W, grid_p2c, mask_u8
-        FC3D_DISPATCH_LAYOUT(project_kernel, layout, fma, true);
+        FC3D_DISPATCH_LAYOUT("warp_project_splat", project_kernel, layout, fma, true);
 #undef ARGS
         FC3D_LAUNCH_CHECK();
     }
@@ -882,7 +882,7 @@ extern "C" int fc3d_warp_p2c_fwd(void* stream, const float* Ip, const float* coo
         int layout = pick_layout(coord_c, c_sc, c_sh, c_sw, W, grid_c2p, Ic_masked);
         if (!aligned4(mask_u8)) layout = kGeneric;
 #define ARGS coord_c, (long)c_sb, (long)c_sc, (long)c_sh, (long)c_sw, T_c2p, Ip, (const uint8_t*)mask_u8, H, W, grid_c2p, Ic_masked
-        FC3D_DISPATCH_LAYOUT(warp_sample_kernel, layout, fma);
+        FC3D_DISPATCH_LAYOUT("warp_sample", warp_sample_kernel, layout, fma);
 #undef ARGS
         FC3D_LAUNCH_CHECK();
     }
@@ -894,7 +894,7 @@ extern "C" int fc3d_points_fwd(void* stream, const float* z, const float* ray_x,
     if (!z || !out || (!ray_dense && (!ray_x || !ray_y))) return FC3D_EINVAL;
     if (int e = check_img(B, H, W)) return e;
     if (!aligned16(out)) return FC3D_EALIGN;
-    hipLaunchKernelGGL(points_fwd_kernel, dim3(cdiv(W, NT), H, B), dim3(NT), 0, (hipStream_t)stream, z, ray_x, ray_y,
+    FC3D_LAUNCH("points_fwd", points_fwd_kernel, dim3(cdiv(W, NT), H, B), dim3(NT), 0, (hipStream_t)stream, z, ray_x, ray_y,
                        ray_dense, (long)ray_sb, H, W, out);
     FC3D_LAUNCH_CHECK();
     return FC3D_OK;
@@ -905,7 +905,7 @@ extern "C" int fc3d_points_bwd(void* stream, const float* g_out, const float* ra
     if (!g_out || !g_z || (!ray_dense && (!ray_x || !ray_y))) return FC3D_EINVAL;
     if (int e = check_img(B, H, W)) return e;
     if (!aligned16(g_out)) return FC3D_EALIGN;
-    hipLaunchKernelGGL(points_bwd_kernel, dim3(cdiv(W, NT), H, B), dim3(NT), 0, (hipStream_t)stream, g_out, ray_x,
+    FC3D_LAUNCH("points_bwd", points_bwd_kernel, dim3(cdiv(W, NT), H, B), dim3(NT), 0, (hipStream_t)stream, g_out, ray_x,
                        ray_y, ray_dense, (long)ray_sb, H, W, g_z);
     FC3D_LAUNCH_CHECK();
     return FC3D_OK;
@@ -917,7 +917,7 @@ extern "C" int fc3d_zp_to_zc_fwd(void* stream, const float* zp, const float* xy,
     if (int e = check_img(B, H, W)) return e;
     if (reinterpret_cast<uintptr_t>(xy) & 7u) return FC3D_EALIGN;
     const long HW = (long)H * W;
-    hipLaunchKernelGGL(zp_to_zc_fwd_kernel, dim3(cdiv(HW, NT), B), dim3(NT), 0, (hipStream_t)stream, zp, xy, inv, HW,
+    FC3D_LAUNCH("zp_to_zc_fwd", zp_to_zc_fwd_kernel, dim3(cdiv(HW, NT), B), dim3(NT), 0, (hipStream_t)stream, zp, xy, inv, HW,
                        zc);
     FC3D_LAUNCH_CHECK();
     return FC3D_OK;
@@ -929,7 +929,7 @@ extern "C" int fc3d_zp_to_zc_bwd(void* stream, const float* g_zc, const float* x
     if (int e = check_img(B, H, W)) return e;
     if (reinterpret_cast<uintptr_t>(xy) & 7u) return FC3D_EALIGN;
     const long HW = (long)H * W;
-    hipLaunchKernelGGL(zp_to_zc_bwd_kernel, dim3(cdiv(HW, NT), B), dim3(NT), 0, (hipStream_t)stream, g_zc, xy, inv, HW,
+    FC3D_LAUNCH("zp_to_zc_bwd", zp_to_zc_bwd_kernel, dim3(cdiv(HW, NT), B), dim3(NT), 0, (hipStream_t)stream, g_zc, xy, inv, HW,
                        g_zp);
     FC3D_LAUNCH_CHECK();
     return FC3D_OK;

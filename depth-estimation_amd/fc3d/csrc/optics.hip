@@ -431,9 +431,8 @@ extern "C" int fc3d_code_pattern_fwd(void* stream, const float* pat0, int64_t pa
     dim3 g(cdiv(W, TX), cdiv(H, TY), B), blk(NT);
     hipStream_t s = (hipStream_t)stream;
     auto k = vec ? code_pattern_fwd_kernel<true> : code_pattern_fwd_kernel<false>;
-    hipLaunchKernelGGL(k, g, blk, lds, s, pat0, (long)pat_sb, (long)pat_sh, (long)pat_sw, z, psf, H, W, Kh, Kw,
-                       conv_flag, cap, grid, raw_out, layer_u8, (unsigned long long*)tilekey_u64);
-    FC3D_LAUNCH_CHECK();
+    FC3D_LAUNCH("code_pattern_fwd", k, g, blk, lds, s, pat0, (long)pat_sb, (long)pat_sh, (long)pat_sw, z, psf, H, W, Kh,
+                Kw, conv_flag, cap, grid, raw_out, layer_u8, (unsigned long long*)tilekey_u64);
     return FC3D_OK;
 }
 
@@ -445,9 +444,8 @@ extern "C" int fc3d_code_pattern_norm(void* stream, const float* raw, const uint
     const bool vec = (((long)H * W) % 4 == 0) && aligned16(raw) && aligned16(out);
     dim3 g(cdiv((long)H * W, NT * 4), B), blk(NT);
     auto k = vec ? code_pattern_norm_kernel<true> : code_pattern_norm_kernel<false>;
-    hipLaunchKernelGGL(k, g, blk, 0, (hipStream_t)stream, raw, (const unsigned long long*)tilekey_u64, ntiles, H, W,
-                       out, max_out, argmax_i32);
-    FC3D_LAUNCH_CHECK();
+    FC3D_LAUNCH("code_pattern_norm", k, g, blk, 0, (hipStream_t)stream, raw, (const unsigned long long*)tilekey_u64,
+                ntiles, H, W, out, max_out, argmax_i32);
     return FC3D_OK;
 }
 
@@ -468,12 +466,11 @@ extern "C" int fc3d_code_pattern_bwd(void* stream, const float* g_out, const flo
     const long HW = (long)H * W;
     const int nred = cdiv(HW, RED_PX);
     float* partial = (float*)workspace;
-    hipLaunchKernelGGL(code_pattern_bwd_reduce_kernel, dim3(nred, B), dim3(NT), 0, s, g_out, out, HW, partial);
-    FC3D_LAUNCH_CHECK();
+    FC3D_LAUNCH("code_pattern_bwd_reduce", code_pattern_bwd_reduce_kernel, dim3(nred, B), dim3(NT), 0, s, g_out, out, HW,
+                partial);
     const bool vec = (W % 4 == 0) && aligned16(g_pat0);
     auto k = vec ? code_pattern_bwd_kernel<true> : code_pattern_bwd_kernel<false>;
-    hipLaunchKernelGGL(k, dim3(cdiv(W, TX), cdiv(H, TY), B), dim3(NT), lds, s, g_out, layer_u8, max_in, argmax_i32,
-                       (const float*)partial, nred, psf, H, W, L, Kh, Kw, conv_flag, cap, g_pat0);
-    FC3D_LAUNCH_CHECK();
+    FC3D_LAUNCH("code_pattern_bwd", k, dim3(cdiv(W, TX), cdiv(H, TY), B), dim3(NT), lds, s, g_out, layer_u8, max_in,
+                argmax_i32, (const float*)partial, nred, psf, H, W, L, Kh, Kw, conv_flag, cap, g_pat0);
     return FC3D_OK;
 }

@@ -166,6 +166,16 @@ int fc3d_zp_to_zc_fwd(void *stream, const float *zp, const float *xy, const floa
 int fc3d_zp_to_zc_bwd(void *stream, const float *g_zc, const float *xy, const float *inv, int B, int H, int W,
                       float *g_zp);
 
+/* ------------------------------------------------------------------------ */
+/* optional per-kernel timing (no counterpart in the reference, which has no   */
+/* profiling hooks): while enabled every kernel launch of this library is       */
+/* bracketed by a HIP event pair on the launching stream.  fc3d_profile_report  */
+/* waits for those events and writes one line per kernel, "name launches        */
+/* total_ms\n", into the HOST buffer buf, then forgets them.                    */
+/* ------------------------------------------------------------------------ */
+int fc3d_profile_enable(int on);
+int fc3d_profile_report(char *buf, size_t len);
+
 #ifdef __cplusplus
 }
 #endif
