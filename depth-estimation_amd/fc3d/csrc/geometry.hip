@@ -94,31 +94,33 @@ __global__ void pose_transforms_kernel(const float* __restrict__ pose, const flo
 // ---------------------------------------------------------------------------------------
 // projection
 // ---------------------------------------------------------------------------------------
-enum CoordLayout { kGeneric = 0, kPlanar4 = 1, kPixel4 = 2 };
+enum CoordLayout { kStrided = 0, kPlanarFlat = 1, kPixel4Flat = 2 };
+// kPlanarFlat : dense planes, component k of flat pixel p at base[k*sc + p]
+// kPixel4Flat : dense [H][W][4] (what z2pointcloud's permuted view points at): one aligned float4 per pixel
+// kStrided    : any other view; (y, x) are recovered from p
 
-// Loads the homogeneous coordinates of 4 neighbouring pixels (x..x+3, row y): c[k][i] is
-// component k of pixel i.
+// Every lane owns 4 pixels that are 64 apart inside its wavefront's run of 256 consecutive
+// pixels, so each load/store/gather instruction of a wavefront touches 64 neighbouring pixels.
+constexpr int PPL = 4;
+constexpr int PX_PER_BLOCK = NT * PPL;
+
+__device__ __forceinline__ long lane_first_pixel() {
+    return (long)blockIdx.x * PX_PER_BLOCK + (threadIdx.x >> 6) * (64 * PPL) + (threadIdx.x & 63);
+}
+
 template <int LAYOUT>
-__device__ __forceinline__ void load_coord4(const float* __restrict__ base, long sc, long sh, long sw, int y,
-                                            int x, int W, float c[4][4]) {
-    if (LAYOUT == kPlanar4) {
+__device__ __forceinline__ void load_coord(const float* __restrict__ base, long sc, long sh, long sw, long p, int W,
+                                           float c[4]) {
+    if (LAYOUT == kPixel4Flat) {
+        const float4 v = *reinterpret_cast<const float4*>(base + p * 4);
+        c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w;
+    } else if (LAYOUT == kPlanarFlat) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float4 v = *reinterpret_cast<const float4*>(base + k * sc + (long)y * sh + x);
-            c[k][0] = v.x; c[k][1] = v.y; c[k][2] = v.z; c[k][3] = v.w;
-        }
-    } else if (LAYOUT == kPixel4) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float4 v = *reinterpret_cast<const float4*>(base + (long)y * sh + (long)(x + i) * 4);
-            c[0][i] = v.x; c[1][i] = v.y; c[2][i] = v.z; c[3][i] = v.w;
-        }
+        for (int k = 0; k < 4; ++k) c[k] = base[k * sc + p];
     } else {
+        const long y = p / W, x = p - y * W;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                c[k][i] = (x + i < W) ? base[k * sc + (long)y * sh + (long)(x + i) * sw] : 1.0f;
+        for (int k = 0; k < 4; ++k) c[k] = base[k * sc + y * sh + x * sw];
     }
 }
 
@@ -150,22 +152,6 @@ __device__ __forceinline__ void project_px(const float* T, float c0, float c1, f
     const float den = __fadd_rn(zu, 1e-10f);
     gx = xu / den;
     gy = yu / den;
-}
-
-__device__ __forceinline__ void store_grid4(float* __restrict__ grid, long pix, int x, int W, bool vec,
-                                            const float gx[4], const float gy[4]) {
-    if (vec) {
-        float4* o = reinterpret_cast<float4*>(grid + pix * 2);
-        o[0] = make_float4(gx[0], gy[0], gx[1], gy[1]);
-        o[1] = make_float4(gx[2], gy[2], gx[3], gy[3]);
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (x + i < W) {
-                grid[(pix + i) * 2 + 0] = gx[i];
-                grid[(pix + i) * 2 + 1] = gy[i];
-            }
-    }
 }
 
 // Marks the pixels a projected point touches (gen_visible_mask).  The flat index is formed
@@ -200,26 +186,28 @@ template <int LAYOUT, bool FMA, bool SPLAT>
 __global__ __launch_bounds__(NT) void project_kernel(const float* __restrict__ coord, long sb, long sc, long sh,
                                                      long sw, const float* __restrict__ Tm, int H, int W,
                                                      float* __restrict__ grid, uint8_t* __restrict__ mask_u8) {
-    const int b = blockIdx.z;
-    const int qpr = (W + 3) >> 2;                       // 4-pixel groups per row
-    const long q4 = (long)blockIdx.x * NT + threadIdx.x;
-    if (q4 >= (long)H * qpr) return;
-    const int y = (int)(q4 / qpr);
-    const int x = (int)(q4 % qpr) * 4;
-    const float* T = Tm + (long)b * 16;
-    float c[4][4];
-    load_coord4<LAYOUT>(coord + (long)b * sb, sc, sh, sw, y, x, W, c);
-    float gx[4], gy[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) project_px<FMA>(T, c[0][i], c[1][i], c[2][i], c[3][i], gx[i], gy[i]);
+    const int b = blockIdx.y;
     const long HW = (long)H * W;
-    const long pix = (long)b * HW + (long)y * W + x;
-    store_grid4(grid, pix, x, W, LAYOUT != kGeneric, gx, gy);
-    if (SPLAT) {
-        uint8_t* m = mask_u8 + (long)b * HW;
+    const long p0 = lane_first_pixel();
+    const float* T = Tm + (long)b * 16;
+    const float* cb = coord + (long)b * sb;
+    float c[PPL][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (x + i < W) splat_px<uint8_t>(m, gx[i], gy[i], W, HW, 0, (uint8_t)1);
+    for (int i = 0; i < PPL; ++i) {
+        const long p = p0 + 64 * i;
+        if (p < HW) load_coord<LAYOUT>(cb, sc, sh, sw, p, W, c[i]);
+    }
+    float2* go = reinterpret_cast<float2*>(grid) + (long)b * HW;
+    uint8_t* m = SPLAT ? mask_u8 + (long)b * HW : nullptr;
+#pragma unroll
+    for (int i = 0; i < PPL; ++i) {
+        const long p = p0 + 64 * i;
+        if (p < HW) {
+            float gx, gy;
+            project_px<FMA>(T, c[i][0], c[i][1], c[i][2], c[i][3], gx, gy);
+            go[p] = make_float2(gx, gy);
+            if (SPLAT) splat_px<uint8_t>(m, gx, gy, W, HW, 0, (uint8_t)1);
+        }
     }
 }
 
@@ -265,36 +253,46 @@ __global__ __launch_bounds__(NT) void warp_sample_kernel(const float* __restrict
                                                          const float* __restrict__ Ip,
                                                          const uint8_t* __restrict__ mask_u8, int H, int W,
                                                          float* __restrict__ grid, float* __restrict__ out) {
-    const int b = blockIdx.z;
-    const int qpr = (W + 3) >> 2;                       // 4-pixel groups per row
-    const long q4 = (long)blockIdx.x * NT + threadIdx.x;
-    if (q4 >= (long)H * qpr) return;
-    const int y = (int)(q4 / qpr);
-    const int x = (int)(q4 % qpr) * 4;
-    const float* T = Tm + (long)b * 16;
-    float c[4][4];
-    load_coord4<LAYOUT>(coord + (long)b * sb, sc, sh, sw, y, x, W, c);
+    const int b = blockIdx.y;
     const long HW = (long)H * W;
-    const long pix = (long)b * HW + (long)y * W + x;
+    const long p0 = lane_first_pixel();
+    const float* T = Tm + (long)b * 16;
+    const float* cb = coord + (long)b * sb;
     const float* img = Ip + (long)b * HW;
-    float gx[4], gy[4], o[4];
+    const uint8_t* mk = mask_u8 + (long)b * HW;
+    float c[PPL][4];
+    float mv[PPL];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        project_px<FMA>(T, c[0][i], c[1][i], c[2][i], c[3][i], gx[i], gy[i]);
-        const Taps t = make_taps(gx[i], gy[i], H, W);
-        const float i00 = img[(long)t.y0 * W + t.x0], i01 = img[(long)t.y1 * W + t.x0];
-        const float i10 = img[(long)t.y0 * W + t.x1], i11 = img[(long)t.y1 * W + t.x1];
-        o[i] = blend(t, i00, i01, i10, i11);
+    for (int i = 0; i < PPL; ++i) {
+        const long p = p0 + 64 * i;
+        if (p < HW) {
+            load_coord<LAYOUT>(cb, sc, sh, sw, p, W, c[i]);
+            mv[i] = (float)mk[p];
+        }
     }
-    store_grid4(grid, pix, x, W, LAYOUT != kGeneric, gx, gy);
-    if (LAYOUT != kGeneric) {
-        const uchar4 m = *reinterpret_cast<const uchar4*>(mask_u8 + pix);
-        *reinterpret_cast<float4*>(out + pix) = make_float4(o[0] * (float)m.x, o[1] * (float)m.y, o[2] * (float)m.z,
-                                                            o[3] * (float)m.w);
-    } else {
+    float2* go = reinterpret_cast<float2*>(grid) + (long)b * HW;
+    float* oo = out + (long)b * HW;
+    float gx[PPL], gy[PPL], i00[PPL], i01[PPL], i10[PPL], i11[PPL];
+    Taps t[PPL];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (x + i < W) out[pix + i] = o[i] * (float)mask_u8[pix + i];
+    for (int i = 0; i < PPL; ++i) {
+        const long p = p0 + 64 * i;
+        if (p < HW) {
+            project_px<FMA>(T, c[i][0], c[i][1], c[i][2], c[i][3], gx[i], gy[i]);
+            t[i] = make_taps(gx[i], gy[i], H, W);
+            i00[i] = img[(long)t[i].y0 * W + t[i].x0];
+            i01[i] = img[(long)t[i].y1 * W + t[i].x0];
+            i10[i] = img[(long)t[i].y0 * W + t[i].x1];
+            i11[i] = img[(long)t[i].y1 * W + t[i].x1];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < PPL; ++i) {
+        const long p = p0 + 64 * i;
+        if (p < HW) {
+            go[p] = make_float2(gx[i], gy[i]);
+            oo[p] = blend(t[i], i00[i], i01[i], i10[i], i11[i]) * mv[i];
+        }
     }
 }
 
@@ -348,18 +346,26 @@ __global__ __launch_bounds__(NT) void bilinear_bwd_grid_kernel(const float* __re
 }
 
 // ---------------------------------------------------------------------------------------
-// d out / d img for C == 1: scatter-add without global atomics
+// d out / d img for C == 1: scatter-add without atomics
 //
-// Pass 1: each wavefront owns a 32x8 tile of target pixels.  It finds the bounding box of
-// the source pixels its taps touch (shuffle min/max), accumulates all taps into a private
-// LDS window of that box, and stores the window compactly ("slab") plus the box.
-// Pass 2: each workgroup owns a 64x16 tile of the source image and adds, in ascending tile
-// order, every slab whose box overlaps it -> the sum order is fixed, results reproducible.
-// Pass 3: tiles whose box did not fit the window (discontinuous warps) are added with
-// global float atomics.
+// Pass 1 (scatter): each wavefront owns a 32x8 tile of target pixels.  It finds the bounding
+//   box of the source pixels its taps touch (DPP min/max), accumulates all taps into a private
+//   LDS window of that box and stores the window compactly ("slab") plus the box.  LDS float
+//   atomics retire about one lane every three cycles on this chip, so the window is updated
+//   with plain read-add-write; lanes of one instruction that hit the same cell are serialised
+//   by an election through a byte-sized owner array (the last writer of a ds_write wins, the
+//   winners add, the rest retry), and LDS executes a wavefront's instructions in order, so
+//   successive taps see each other's updates.
+// Pass 2 (merge): each workgroup owns a 64x16 tile of the source image and adds, in ascending
+//   tile order, every slab whose box overlaps it -> fixed summation order, reproducible bits.
+// Pass 3 (overflow): tiles whose box did not fit a window (discontinuous warps) are added with
+//   global float atomics.
+//
+// A sample whose two x corners (or two y corners) were clamped onto the same source pixel
+// contributes +w and -w to that pixel, i.e. exactly nothing; such samples are skipped.
 // ---------------------------------------------------------------------------------------
 constexpr int WT_X = 32, WT_Y = 8;       // wavefront tile
-constexpr int WIN_CAP = 2048;            // floats per window / slab
+constexpr int WIN_CAP = 1024;            // cells per window / floats per slab
 
 struct TileMeta { int xmin, ymin, ww, wh; };   // ww = 0: empty, ww = -1: overflow
 
@@ -369,23 +375,69 @@ struct PxTaps {
     bool on;
 };
 
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_move(int old, int src) {
+    return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xf, false);
+}
+// Wave-wide min/max through the data-parallel-primitive path (no LDS traffic): prefix-doubling
+// inside each row of 16 lanes, then row broadcasts; lane 63 ends up with the full result.
+__device__ __forceinline__ int wave_min_dpp(int v) {
+    const int id = 0x7fffffff;
+    v = min(v, dpp_move<0x111, 0xf>(id, v));   // row_shr:1
+    v = min(v, dpp_move<0x112, 0xf>(id, v));   // row_shr:2
+    v = min(v, dpp_move<0x114, 0xf>(id, v));   // row_shr:4
+    v = min(v, dpp_move<0x118, 0xf>(id, v));   // row_shr:8
+    v = min(v, dpp_move<0x142, 0xa>(id, v));   // row_bcast:15 into rows 1,3
+    v = min(v, dpp_move<0x143, 0xc>(id, v));   // row_bcast:31 into rows 2,3
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ int wave_max_dpp(int v) {
+    const int id = (int)0x80000000;
+    v = max(v, dpp_move<0x111, 0xf>(id, v));
+    v = max(v, dpp_move<0x112, 0xf>(id, v));
+    v = max(v, dpp_move<0x114, 0xf>(id, v));
+    v = max(v, dpp_move<0x118, 0xf>(id, v));
+    v = max(v, dpp_move<0x142, 0xa>(id, v));
+    v = max(v, dpp_move<0x143, 0xc>(id, v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 __device__ __forceinline__ void load_tile_taps(const float* __restrict__ g_out, const float* __restrict__ grid,
                                                const uint8_t* __restrict__ mask_u8, long tb, int Ht, int Wt, int Hs,
                                                int Ws, int tx0, int ty0, int lane, PxTaps px[4]) {
     const int x = tx0 + (lane & 31);
+    float2 g[4];
+    bool vis[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int y = ty0 + (lane >> 5) + 2 * k;
-        px[k].on = false;
+        vis[k] = (x < Wt) && (y < Ht);
         px[k].v = 0.0f;
-        if (x < Wt && y < Ht) {
+        g[k] = make_float2(0.f, 0.f);
+        if (vis[k]) {
             const long q = tb + (long)y * Wt + x;
-            const bool vis = mask_u8 ? (mask_u8[q] != 0) : true;
-            if (vis) {
-                const float2 g = *reinterpret_cast<const float2*>(grid + q * 2);
-                px[k].t = make_taps(g.x, g.y, Hs, Ws);
-                px[k].v = g_out[q];
-                px[k].on = true;
+            if (mask_u8) vis[k] = mask_u8[q] != 0;
+            g[k] = *reinterpret_cast<const float2*>(grid + q * 2);
+            px[k].v = g_out[q];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        px[k].t = make_taps(g[k].x, g[k].y, Hs, Ws);
+        px[k].on = vis[k] && (px[k].t.x0 != px[k].t.x1) && (px[k].t.y0 != px[k].t.y1);
+    }
+}
+
+// win[cell] += val for every active lane; lanes aiming at the same cell take turns.
+__device__ __forceinline__ void window_add(volatile float* win, volatile uint8_t* own, int cell, float val,
+                                           bool active, int lane) {
+    bool pend = active;
+    while (__ballot(pend)) {
+        if (pend) {
+            own[cell] = (uint8_t)lane;
+            if (own[cell] == (uint8_t)lane) {      // LDS runs a wavefront's ds ops in order: this reads the winner
+                win[cell] = win[cell] + val;
+                pend = false;
             }
         }
     }
@@ -394,72 +446,100 @@ __device__ __forceinline__ void load_tile_taps(const float* __restrict__ g_out, 
 __global__ __launch_bounds__(NT) void bilinear_bwd_img_scatter_kernel(
     const float* __restrict__ g_out, const float* __restrict__ grid, const uint8_t* __restrict__ mask_u8, int Hs,
     int Ws, int Ht, int Wt, int tiles_x, int ntiles, TileMeta* __restrict__ meta, float* __restrict__ slab) {
-    __shared__ float win[NT / 64][WIN_CAP];
+    __shared__ float s_win[NT / 64][WIN_CAP];
+    __shared__ uint8_t s_own[NT / 64][WIN_CAP];
     const int b = blockIdx.y;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int t = blockIdx.x * (NT / 64) + wv;
-    const bool live = t < ntiles;
-    const int tx0 = live ? (t % tiles_x) * WT_X : 0, ty0 = live ? (t / tiles_x) * WT_Y : Ht;
+    if (t >= ntiles) return;                       // no workgroup barrier below: wavefronts are independent
+    const int tx0 = (t % tiles_x) * WT_X, ty0 = (t / tiles_x) * WT_Y;
     PxTaps px[4];
     load_tile_taps(g_out, grid, mask_u8, (long)b * Ht * Wt, Ht, Wt, Hs, Ws, tx0, ty0, lane, px);
-    int xmin = 1 << 30, ymin = 1 << 30, xmax = -1, ymax = -1;
+    int xmin = 0x7fffffff, ymin = 0x7fffffff, xmax = -1, ymax = -1;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         if (px[k].on) {
             xmin = min(xmin, px[k].t.x0); xmax = max(xmax, px[k].t.x1);
             ymin = min(ymin, px[k].t.y0); ymax = max(ymax, px[k].t.y1);
         }
-    xmin = wave_min(xmin); ymin = wave_min(ymin);
-    xmax = wave_max(xmax); ymax = wave_max(ymax);
+    xmin = wave_min_dpp(xmin); ymin = wave_min_dpp(ymin);
+    xmax = wave_max_dpp(xmax); ymax = wave_max_dpp(ymax);
     const bool empty = xmax < 0;
     const int ww = empty ? 0 : xmax - xmin + 1, wh = empty ? 0 : ymax - ymin + 1;
     const bool fits = (long)ww * wh <= WIN_CAP;
     const int n = fits ? ww * wh : 0;
-    float* w = win[wv];
+    volatile float* w = s_win[wv];
+    volatile uint8_t* own = s_own[wv];
     for (int i = lane; i < n; i += 64) w[i] = 0.0f;
-    __syncthreads();
-    if (fits && !empty) {
+    if (n > 0) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (px[k].on) {
-                const Taps& tp = px[k].t;
-                const int r0 = (tp.y0 - ymin) * ww, r1 = (tp.y1 - ymin) * ww;
-                const int c0 = tp.x0 - xmin, c1 = tp.x1 - xmin;
-                atomicAdd(&w[r0 + c0], (tp.wx0 * tp.wy0) * px[k].v);
-                atomicAdd(&w[r1 + c0], (tp.wx0 * tp.wy1) * px[k].v);
-                atomicAdd(&w[r0 + c1], (tp.wx1 * tp.wy0) * px[k].v);
-                atomicAdd(&w[r1 + c1], (tp.wx1 * tp.wy1) * px[k].v);
-            }
-    }
-    __syncthreads();
-    if (live) {
-        const long tg = (long)b * ntiles + t;
-        float* s = slab + tg * WIN_CAP;
-        for (int i = lane; i < n; i += 64) s[i] = w[i];
-        if (lane == 0) {
-            TileMeta m;
-            m.xmin = xmin; m.ymin = ymin; m.ww = fits ? ww : -1; m.wh = wh;
-            if (empty) { m.xmin = 0; m.ymin = 0; m.ww = 0; m.wh = 0; }
-            meta[tg] = m;
+        for (int k = 0; k < 4; ++k) {
+            const Taps& tp = px[k].t;
+            const bool on = px[k].on;
+            const int r0 = on ? (tp.y0 - ymin) * ww : 0, r1 = on ? (tp.y1 - ymin) * ww : 0;
+            const int c0 = on ? tp.x0 - xmin : 0, c1 = on ? tp.x1 - xmin : 0;
+            window_add(w, own, r0 + c0, (tp.wx0 * tp.wy0) * px[k].v, on, lane);
+            window_add(w, own, r1 + c0, (tp.wx0 * tp.wy1) * px[k].v, on, lane);
+            window_add(w, own, r0 + c1, (tp.wx1 * tp.wy0) * px[k].v, on, lane);
+            window_add(w, own, r1 + c1, (tp.wx1 * tp.wy1) * px[k].v, on, lane);
         }
+    }
+    const long tg = (long)b * ntiles + t;
+    float* s = slab + tg * WIN_CAP;
+    for (int i = lane; i < n; i += 64) s[i] = w[i];
+    if (lane == 0) {
+        TileMeta m;
+        m.xmin = empty ? 0 : xmin; m.ymin = empty ? 0 : ymin;
+        m.ww = empty ? 0 : (fits ? ww : -1); m.wh = wh;
+        meta[tg] = m;
     }
 }
 
 constexpr int MT_X = 64, MT_Y = 16;      // merge tile of the source image
+constexpr int LIST_CAP = 512;
 
 __global__ __launch_bounds__(NT) void bilinear_bwd_img_merge_kernel(const TileMeta* __restrict__ meta,
                                                                     const float* __restrict__ slab, int ntiles,
                                                                     int Hs, int Ws, float* __restrict__ g_img) {
-    __shared__ TileMeta s_list[NT];
-    __shared__ int s_tile[NT];
+    __shared__ TileMeta s_list[LIST_CAP];
+    __shared__ int s_tile[LIST_CAP];
     __shared__ int s_wcnt[NT / 64];
     const int b = blockIdx.z;
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const int bx0 = blockIdx.x * MT_X, by0 = blockIdx.y * MT_Y;
-    const int x = bx0 + (tid & 15) * 4, y = by0 + (tid >> 4);
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const int x = bx0 + lane;                       // a wavefront reads 64 neighbouring pixels of a row
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};            // rows by0 + wv + 4*i
     const TileMeta* mb = meta + (long)b * ntiles;
     const float* sb = slab + (long)b * ntiles * WIN_CAP;
+    int count = 0;
+
+    auto flush = [&](int total) {
+        for (int j0 = 0; j0 < total; j0 += 4) {
+            float v[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u;
+                TileMeta e = {0, 0, 0, 0};
+                const float* base = sb;
+                if (j < total) {
+                    e = s_list[j];
+                    base = sb + (long)s_tile[j] * WIN_CAP;
+                }
+                const int cx = x - e.xmin;
+                const bool inx = (cx >= 0) && (cx < e.ww);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int ry = by0 + wv + 4 * i - e.ymin;
+                    v[u][i] = (inx && ry >= 0 && ry < e.wh) ? base[ry * e.ww + cx] : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] += v[u][i];   // ascending tile order, u after u
+        }
+    };
+
     for (int base = 0; base < ntiles; base += NT) {
         const int t = base + tid;
         TileMeta m = {0, 0, 0, 0};
@@ -472,7 +552,7 @@ __global__ __launch_bounds__(NT) void bilinear_bwd_img_merge_kernel(const TileMe
         const unsigned long long bal = __ballot(hit);
         if (lane == 0) s_wcnt[wv] = __popcll(bal);
         __syncthreads();
-        int off = 0, total = 0;
+        int off = count, total = count;
 #pragma unroll
         for (int i = 0; i < NT / 64; ++i) {
             if (i < wv) off += s_wcnt[i];
@@ -484,29 +564,17 @@ __global__ __launch_bounds__(NT) void bilinear_bwd_img_merge_kernel(const TileMe
             s_tile[pos] = t;
         }
         __syncthreads();
-        for (int j = 0; j < total; ++j) {
-            const TileMeta e = s_list[j];
-            const int ry = y - e.ymin;
-            if (ry >= 0 && ry < e.wh) {
-                const float* row = sb + (long)s_tile[j] * WIN_CAP + ry * e.ww - e.xmin;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int cx = x + i - e.xmin;
-                    if (cx >= 0 && cx < e.ww) acc[i] += row[x + i];
-                }
-            }
+        count = total;
+        if (count > LIST_CAP - NT || base + NT >= ntiles) {
+            flush(count);
+            count = 0;
+            __syncthreads();
         }
-        __syncthreads();
     }
-    if (y < Hs) {
-        float* o = g_img + (long)b * Hs * Ws + (long)y * Ws + x;
-        if ((Ws & 3) == 0 && x < Ws) {
-            *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (x + i < Ws) o[i] = acc[i];
-        }
+    for (int i = 0; i < 4; ++i) {
+        const int y = by0 + wv + 4 * i;
+        if (y < Hs && x < Ws) g_img[(long)b * Hs * Ws + (long)y * Ws + x] = acc[i];
     }
 }
 
@@ -652,54 +720,38 @@ __global__ __launch_bounds__(NT) void project_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ coord, long sb, long sc, long sh,
                                                          long sw, const float* __restrict__ Tm, int H, int W,
                                                          float* __restrict__ g_coord) {
-    const int b = blockIdx.z;
-    const int qpr = (W + 3) >> 2;                       // 4-pixel groups per row
-    const long q4 = (long)blockIdx.x * NT + threadIdx.x;
-    if (q4 >= (long)H * qpr) return;
-    const int y = (int)(q4 / qpr);
-    const int x = (int)(q4 % qpr) * 4;
-    const float* T = Tm + (long)b * 16;
-    float c[4][4];
-    load_coord4<LAYOUT>(coord + (long)b * sb, sc, sh, sw, y, x, W, c);
+    const int b = blockIdx.y;
     const long HW = (long)H * W;
-    const long pix = (long)b * HW + (long)y * W + x;
-    float go[4][4];
+    const long p0 = lane_first_pixel();
+    const float* T = Tm + (long)b * 16;
+    const float* cb = coord + (long)b * sb;
+    const float2* gg = reinterpret_cast<const float2*>(g_grid) + (long)b * HW;
+    float* o = g_coord + (long)b * 4 * HW;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (x + i >= W) continue;
-        const float xu = row_dot<FMA>(T + 0, c[0][i], c[1][i], c[2][i], c[3][i]);
-        const float yu = row_dot<FMA>(T + 4, c[0][i], c[1][i], c[2][i], c[3][i]);
-        const float zu = row_dot<FMA>(T + 8, c[0][i], c[1][i], c[2][i], c[3][i]);
+    for (int i = 0; i < PPL; ++i) {
+        const long p = p0 + 64 * i;
+        if (p >= HW) continue;
+        float c[4];
+        load_coord<LAYOUT>(cb, sc, sh, sw, p, W, c);
+        const float xu = row_dot<FMA>(T + 0, c[0], c[1], c[2], c[3]);
+        const float yu = row_dot<FMA>(T + 4, c[0], c[1], c[2], c[3]);
+        const float zu = row_dot<FMA>(T + 8, c[0], c[1], c[2], c[3]);
         const float den = zu + 1e-10f;
-        const float ggx = g_grid[(pix + i) * 2 + 0], ggy = g_grid[(pix + i) * 2 + 1];
-        const float gxu = ggx / den, gyu = ggy / den;
-        const float gzu = -(ggx * xu + ggy * yu) / (den * den);
+        const float2 g = gg[p];
+        const float gxu = g.x / den, gyu = g.y / den;
+        const float gzu = -(g.x * xu + g.y * yu) / (den * den);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) go[k][i] = T[0 + k] * gxu + T[4 + k] * gyu + T[8 + k] * gzu;
-    }
-    float* o = g_coord + (long)b * 4 * HW + (long)y * W + x;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (LAYOUT != kGeneric) {
-            *reinterpret_cast<float4*>(o + k * HW) = make_float4(go[k][0], go[k][1], go[k][2], go[k][3]);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (x + i < W) o[k * HW + i] = go[k][i];
-        }
+        for (int k = 0; k < 4; ++k) o[k * HW + p] = T[0 + k] * gxu + T[4 + k] * gyu + T[8 + k] * gzu;
     }
 }
 
 // ---------------------------------------------------------------------------------------
 // host helpers
 // ---------------------------------------------------------------------------------------
-static int pick_layout(const float* coord, int64_t sc, int64_t sh, int64_t sw, int W, const float* out_a,
-                       const float* out_b) {
-    const bool outs_ok = (W % 4 == 0) && aligned16(out_a) && (!out_b || aligned16(out_b));
-    if (!outs_ok || !aligned16(coord)) return kGeneric;
-    if (sw == 1 && sh % 4 == 0 && sc % 4 == 0) return kPlanar4;
-    if (sc == 1 && sw == 4 && sh % 4 == 0) return kPixel4;
-    return kGeneric;
+static int pick_layout(const float* coord, int64_t sc, int64_t sh, int64_t sw, int W) {
+    if (sw == 1 && sh == W) return kPlanarFlat;
+    if (sc == 1 && sw == 4 && sh == 4L * W && aligned16(coord)) return kPixel4Flat;
+    return kStrided;
 }
 
 static int check_img(int B, int H, int W) {
@@ -714,13 +766,13 @@ static inline bool use_fma(int H, int W) { return 16L * H * W >= 400; }
 #define FC3D_DISPATCH_LAYOUT(NAME, KERNEL, layout, fma, ...)                                                     \
     do {                                                                                                   \
         if (fma) {                                                                                         \
-            if (layout == kPlanar4) FC3D_LAUNCH(NAME, (KERNEL<kPlanar4, true, ##__VA_ARGS__>), g, blk, 0, s, ARGS); \
-            else if (layout == kPixel4) FC3D_LAUNCH(NAME, (KERNEL<kPixel4, true, ##__VA_ARGS__>), g, blk, 0, s, ARGS); \
-            else FC3D_LAUNCH(NAME, (KERNEL<kGeneric, true, ##__VA_ARGS__>), g, blk, 0, s, ARGS);           \
+            if (layout == kPlanarFlat) FC3D_LAUNCH(NAME, (KERNEL<kPlanarFlat, true, ##__VA_ARGS__>), g, blk, 0, s, ARGS); \
+            else if (layout == kPixel4Flat) FC3D_LAUNCH(NAME, (KERNEL<kPixel4Flat, true, ##__VA_ARGS__>), g, blk, 0, s, ARGS); \
+            else FC3D_LAUNCH(NAME, (KERNEL<kStrided, true, ##__VA_ARGS__>), g, blk, 0, s, ARGS);           \
         } else {                                                                                           \
-            if (layout == kPlanar4) FC3D_LAUNCH(NAME, (KERNEL<kPlanar4, false, ##__VA_ARGS__>), g, blk, 0, s, ARGS); \
-            else if (layout == kPixel4) FC3D_LAUNCH(NAME, (KERNEL<kPixel4, false, ##__VA_ARGS__>), g, blk, 0, s, ARGS); \
-            else FC3D_LAUNCH(NAME, (KERNEL<kGeneric, false, ##__VA_ARGS__>), g, blk, 0, s, ARGS);          \
+            if (layout == kPlanarFlat) FC3D_LAUNCH(NAME, (KERNEL<kPlanarFlat, false, ##__VA_ARGS__>), g, blk, 0, s, ARGS); \
+            else if (layout == kPixel4Flat) FC3D_LAUNCH(NAME, (KERNEL<kPixel4Flat, false, ##__VA_ARGS__>), g, blk, 0, s, ARGS); \
+            else FC3D_LAUNCH(NAME, (KERNEL<kStrided, false, ##__VA_ARGS__>), g, blk, 0, s, ARGS);          \
         }                                                                                                  \
     } while (0)
 
@@ -742,9 +794,10 @@ extern "C" int fc3d_project_fwd(void* stream, const float* coord, int64_t sb, in
                                 const float* T, int B, int H, int W, float* grid_out) {
     if (!coord || !T || !grid_out) return FC3D_EINVAL;
     if (int e = check_img(B, H, W)) return e;
-    const int layout = pick_layout(coord, sc, sh, sw, W, grid_out, nullptr);
+    if (!aligned4(coord) || (reinterpret_cast<uintptr_t>(grid_out) & 7u)) return FC3D_EALIGN;
+    const int layout = pick_layout(coord, sc, sh, sw, W);
     const bool fma = use_fma(H, W);
-    dim3 g(cdiv((long)H * cdiv(W, 4), NT), 1, B), blk(NT);
+    dim3 g(cdiv((long)H * W, PX_PER_BLOCK), B), blk(NT);
     hipStream_t s = (hipStream_t)stream;
     uint8_t* nomask = nullptr;
 #define ARGS coord, (long)sb, (long)sc, (long)sh, (long)sw, T, H, W, grid_out, nomask
@@ -758,9 +811,10 @@ extern "C" int fc3d_project_bwd(void* stream, const float* g_grid, const float* 
                                 int64_t sh, int64_t sw, const float* T, int B, int H, int W, float* g_coord) {
     if (!g_grid || !coord || !T || !g_coord) return FC3D_EINVAL;
     if (int e = check_img(B, H, W)) return e;
-    const int layout = pick_layout(coord, sc, sh, sw, W, g_coord, nullptr);
+    if (!aligned4(coord) || !aligned4(g_coord) || (reinterpret_cast<uintptr_t>(g_grid) & 7u)) return FC3D_EALIGN;
+    const int layout = pick_layout(coord, sc, sh, sw, W);
     const bool fma = use_fma(H, W);
-    dim3 g(cdiv((long)H * cdiv(W, 4), NT), 1, B), blk(NT);
+    dim3 g(cdiv((long)H * W, PX_PER_BLOCK), B), blk(NT);
     hipStream_t s = (hipStream_t)stream;
 #define ARGS g_grid, coord, (long)sb, (long)sc, (long)sh, (long)sw, T, H, W, g_coord
     FC3D_DISPATCH_LAYOUT("project_bwd", project_bwd_kernel, layout, fma);
@@ -867,20 +921,22 @@ extern "C" int fc3d_warp_p2c_fwd(void* stream, const float* Ip, const float* coo
     if (!Ip || !coord_p || !coord_c || !T_p2c || !T_c2p || !Ic_masked || !grid_p2c || !grid_c2p || !mask_u8)
         return FC3D_EINVAL;
     if (int e = check_img(B, H, W)) return e;
+    if (!aligned4(coord_p) || !aligned4(coord_c) || !aligned4(Ip) || !aligned4(Ic_masked) ||
+        (reinterpret_cast<uintptr_t>(grid_p2c) & 7u) || (reinterpret_cast<uintptr_t>(grid_c2p) & 7u))
+        return FC3D_EALIGN;
     hipStream_t s = (hipStream_t)stream;
     const bool fma = use_fma(H, W);
-    dim3 g(cdiv((long)H * cdiv(W, 4), NT), 1, B), blk(NT);
+    dim3 g(cdiv((long)H * W, PX_PER_BLOCK), B), blk(NT);
     FC3D_HIP(hipMemsetAsync(mask_u8, 0, (size_t)B * H * W, s));
     {
-        const int layout = pick_layout(coord_p, p_sc, p_sh, p_sw, W, grid_p2c, nullptr);
+        const int layout = pick_layout(coord_p, p_sc, p_sh, p_sw, W);
 #define ARGS coord_p, (long)p_sb, (long)p_sc, (long)p_sh, (long)p_sw, T_p2c, H, W, grid_p2c, mask_u8
         FC3D_DISPATCH_LAYOUT("warp_project_splat", project_kernel, layout, fma, true);
 #undef ARGS
         FC3D_LAUNCH_CHECK();
     }
     {
-        int layout = pick_layout(coord_c, c_sc, c_sh, c_sw, W, grid_c2p, Ic_masked);
-        if (!aligned4(mask_u8)) layout = kGeneric;
+        const int layout = pick_layout(coord_c, c_sc, c_sh, c_sw, W);
 #define ARGS coord_c, (long)c_sb, (long)c_sc, (long)c_sh, (long)c_sw, T_c2p, Ip, (const uint8_t*)mask_u8, H, W, grid_c2p, Ic_masked
         FC3D_DISPATCH_LAYOUT("warp_sample", warp_sample_kernel, layout, fma);
 #undef ARGS

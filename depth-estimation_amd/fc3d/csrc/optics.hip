@@ -270,6 +270,7 @@ __device__ __forceinline__ float block_sum(float v, float* s_red) {
     return t;
 }
 
+template <bool VEC>
 __global__ __launch_bounds__(NT) void code_pattern_bwd_reduce_kernel(
     const float* __restrict__ g, const float* __restrict__ out, long HW, float* __restrict__ partial) {
     __shared__ float s_red[NT / 64];
@@ -277,8 +278,16 @@ __global__ __launch_bounds__(NT) void code_pattern_bwd_reduce_kernel(
     const long base = (long)b * HW;
     const long i0 = ((long)blockIdx.x * NT + threadIdx.x) * 4;
     float s = 0.0f;
-    for (int k = 0; k < 4; ++k)
-        if (i0 + k < HW) s = fmaf(g[base + i0 + k], out[base + i0 + k], s);
+    if (VEC) {
+        if (i0 < HW) {
+            const float4 a = *reinterpret_cast<const float4*>(g + base + i0);
+            const float4 c = *reinterpret_cast<const float4*>(out + base + i0);
+            s = fmaf(a.x, c.x, s); s = fmaf(a.y, c.y, s); s = fmaf(a.z, c.z, s); s = fmaf(a.w, c.w, s);
+        }
+    } else {
+        for (int k = 0; k < 4; ++k)
+            if (i0 + k < HW) s = fmaf(g[base + i0 + k], out[base + i0 + k], s);
+    }
     s = block_sum(s, s_red);
     if (threadIdx.x == 0) partial[(long)b * gridDim.x + blockIdx.x] = s;
 }
@@ -466,8 +475,9 @@ extern "C" int fc3d_code_pattern_bwd(void* stream, const float* g_out, const flo
     const long HW = (long)H * W;
     const int nred = cdiv(HW, RED_PX);
     float* partial = (float*)workspace;
-    FC3D_LAUNCH("code_pattern_bwd_reduce", code_pattern_bwd_reduce_kernel, dim3(nred, B), dim3(NT), 0, s, g_out, out, HW,
-                partial);
+    const bool rvec = (HW % 4 == 0) && aligned16(g_out) && aligned16(out);
+    auto kr = rvec ? code_pattern_bwd_reduce_kernel<true> : code_pattern_bwd_reduce_kernel<false>;
+    FC3D_LAUNCH("code_pattern_bwd_reduce", kr, dim3(nred, B), dim3(NT), 0, s, g_out, out, HW, partial);
     const bool vec = (W % 4 == 0) && aligned16(g_pat0);
     auto k = vec ? code_pattern_bwd_kernel<true> : code_pattern_bwd_kernel<false>;
     FC3D_LAUNCH("code_pattern_bwd", k, dim3(cdiv(W, TX), cdiv(H, TY), B), dim3(NT), lds, s, g_out, layer_u8, max_in,

@@ -91,10 +91,13 @@ class CodePatternFn(torch.autograd.Function):
         ctx.save_for_backward(out, layer, mx, am, psf)
         ctx.meta = (B, H, W, L, Kh, Kw, conv)
         ctx.mark_non_differentiable(layer, mx, am)
+        ctx.set_materialize_grads(False)      # no zero tensors for the auxiliary outputs
         return out, layer, mx, am
 
     @staticmethod
     def backward(ctx, g_out, _gl, _gm, _ga):
+        if g_out is None:
+            return None, None, None, None, None
         out, layer, mx, am, psf = ctx.saved_tensors
         B, H, W, L, Kh, Kw, conv = ctx.meta
         g = _dense(g_out)
@@ -270,10 +273,13 @@ class WarpP2CFn(torch.autograd.Function):
                                           mask.data_ptr()), "fc3d_warp_p2c_fwd")
         ctx.save_for_backward(gc2p, mask)
         ctx.mark_non_differentiable(gp2c, gc2p, mask)
+        ctx.set_materialize_grads(False)      # no zero tensors for the two grids and the mask
         return Ic, gp2c, gc2p, mask
 
     @staticmethod
     def backward(ctx, g_Ic, _g1, _g2, _g3):
+        if g_Ic is None:
+            return None, None, None, None, None
         gc2p, mask = ctx.saved_tensors
         B, H, W, _ = gc2p.shape
         gi = _bilinear_bwd_img(_dense(g_Ic), gc2p, mask, B, H, W, 1, H, W)

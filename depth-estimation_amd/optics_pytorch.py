@@ -16,6 +16,7 @@ Differences a caller can observe:
 from __future__ import annotations
 
 import os
+import sys
 
 import numpy as np
 import torch
@@ -35,7 +36,7 @@ fn_psfs = 'psfs_exp.npy'
 if os.path.exists(fn_psfs):
     PSFs_np = np.load(fn_psfs)
 else:
-    print(f"Warning: {fn_psfs} not found. Using dummy PSFs.")
+    print(f"Warning: {fn_psfs} not found. Using dummy PSFs.", file=sys.stderr)   # the reference prints to stdout
     PSFs_np = np.ones((21, 5, 5, 1), dtype=np.float32)
 
 _psf_cache: dict = {}
