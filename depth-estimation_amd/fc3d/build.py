@@ -40,15 +40,16 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True, extra_flags=()) -> str:
-    if not force and not needs_build():
+def build(force: bool = False, verbose: bool = True, extra_flags=(), out: str = LIB) -> str:
+    """extra_flags / out: experiment builds (e.g. -D switches) into another file."""
+    if not force and out == LIB and not needs_build():
         return LIB
     cmd = [_hipcc(), *FLAGS, *extra_flags, "-I", os.path.join(ROOT, "include"), "-I", CSRC,
-           *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB]
+           *[os.path.join(CSRC, s) for s in SOURCES], "-o", out]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB
+    return out
 
 
 if __name__ == "__main__":

@@ -159,11 +159,17 @@ __device__ __forceinline__ void project_px(const float* T, float c0, float c1, f
 // outside the row wraps into the neighbouring row.  Idempotent byte/float stores of "1"
 // need no atomics and give a bit-exact, order-independent mask.
 template <typename MaskT>
-__device__ __forceinline__ void mark(MaskT* __restrict__ m, float xi, float yi, float Wf, long HW, MaskT one) {
-    const float f = __fadd_rn(xi, __fmul_rn(yi, Wf));
-    if (!(fabsf(f) < 9.0e18f)) return;          // NaN / Inf / beyond int64: the reference's cast yields a negative index
-    const long idx = (long)f;
-    if (idx >= 0 && idx < HW) m[idx] = one;
+__device__ __forceinline__ void mark(MaskT* __restrict__ m, float xi, float yW, long HW, MaskT one) {
+    const float f = __fadd_rn(xi, yW);           // integer-valued (or NaN/Inf): a sum of floor/ceil/round results
+    if (HW <= (1L << 24)) {
+        // every valid index is exactly representable, so the range test can stay in fp32 and the
+        // index in 32 bits (NaN fails both comparisons)
+        if (f >= 0.0f && f < (float)HW) m[(int)f] = one;
+    } else {
+        if (!(fabsf(f) < 9.0e18f)) return;       // NaN / Inf / beyond int64: the reference's cast yields a negative index
+        const long idx = (long)f;
+        if (idx >= 0 && idx < HW) m[idx] = one;
+    }
 }
 
 template <typename MaskT>
@@ -171,13 +177,14 @@ __device__ __forceinline__ void splat_px(MaskT* __restrict__ m, float gx, float 
                                          MaskT one) {
     const float Wf = (float)W;
     if (method == 0) {
-        const float fx = floorf(gx), cx = ceilf(gx), fy = floorf(gy), cy = ceilf(gy);
-        mark(m, fx, fy, Wf, HW, one);
-        mark(m, fx, cy, Wf, HW, one);
-        mark(m, cx, fy, Wf, HW, one);
-        mark(m, cx, cy, Wf, HW, one);
+        const float fx = floorf(gx), cx = ceilf(gx);
+        const float fyW = __fmul_rn(floorf(gy), Wf), cyW = __fmul_rn(ceilf(gy), Wf);
+        mark(m, fx, fyW, HW, one);
+        mark(m, fx, cyW, HW, one);
+        mark(m, cx, fyW, HW, one);
+        mark(m, cx, cyW, HW, one);
     } else {
-        mark(m, rintf(gx), rintf(gy), Wf, HW, one);
+        mark(m, rintf(gx), __fmul_rn(rintf(gy), Wf), HW, one);
     }
 }
 

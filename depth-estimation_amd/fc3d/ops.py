@@ -6,6 +6,8 @@ is deliberately no CPU path.
 """
 from __future__ import annotations
 
+import ctypes
+
 import numpy as np
 import torch
 
@@ -81,13 +83,15 @@ class CodePatternFn(torch.autograd.Function):
         mx = torch.empty(B, dtype=torch.float32, device=dev)
         am = torch.empty(B, dtype=torch.int32, device=dev)
         s = _stream()
+        nkeys = ctypes.c_int(0)
         with torch.cuda.device(dev):
             _check(_lib.fc3d_code_pattern_fwd(s, pat0.data_ptr(), pat0.stride(0), pat0.stride(1), pat0.stride(2),
                                               z.data_ptr(), psf.data_ptr() if conv else None, B, H, W, Kh, Kw,
-                                              int(conv), grid, out.data_ptr(), layer.data_ptr(), keys.data_ptr()),
-                   "fc3d_code_pattern_fwd")
-            _check(_lib.fc3d_code_pattern_norm(s, out.data_ptr(), keys.data_ptr(), B, H, W, out.data_ptr(),
-                                               mx.data_ptr(), am.data_ptr()), "fc3d_code_pattern_norm")
+                                              int(conv), grid, out.data_ptr(), layer.data_ptr(), keys.data_ptr(),
+                                              ctypes.byref(nkeys)), "fc3d_code_pattern_fwd")
+            _check(_lib.fc3d_code_pattern_norm(s, out.data_ptr(), keys.data_ptr(), nkeys.value, B, H, W,
+                                               out.data_ptr(), mx.data_ptr(), am.data_ptr()),
+                   "fc3d_code_pattern_norm")
         ctx.save_for_backward(out, layer, mx, am, psf)
         ctx.meta = (B, H, W, L, Kh, Kw, conv)
         ctx.mark_non_differentiable(layer, mx, am)

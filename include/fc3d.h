@@ -71,19 +71,20 @@ size_t fc3d_code_pattern_bwd_workspace(int B, int H, int W);
  *               ignored when conv_flag == 0 (the is_conv_psf=False branch :110-112)
  *   raw_out     [B][H][W]  sum_l conv_l * mask_l                  (:115)
  *   layer_u8    [B][H][W]  layer index, 255 = no layer (may be NULL)
- *   tilekey_u64 fc3d_code_pattern_fwd_workspace() bytes: one packed key per 64x16
+ *   tilekey_u64 fc3d_code_pattern_fwd_workspace() bytes: one packed key per output
  *               tile (ordered max value | first-w-then-h position priority), fully
  *               overwritten.  Zero 'same' padding: (K-1)/2 before, the rest after.  */
 int fc3d_code_pattern_fwd(void *stream, const float *pat0, int64_t pat_sb, int64_t pat_sh, int64_t pat_sw,
                           const float *z, const float *psf, int B, int H, int W, int Kh, int Kw,
                           int conv_flag, fc3d_layer_grid grid,
-                          float *raw_out, uint8_t *layer_u8, uint64_t *tilekey_u64);
+                          float *raw_out, uint8_t *layer_u8, uint64_t *tilekey_u64,
+                          int *keys_per_image /* HOST, out: keys written per image; pass to _norm */);
 
 /* Forward, second half: out = raw / (max + 1e-10) per image, in place allowed
  * (optics_pytorch.py:118-119).  Also unpacks max_out[B] and argmax_i32[B]
  * (flat y*W+x of the pixel that receives the max's gradient).                 */
-int fc3d_code_pattern_norm(void *stream, const float *raw, const uint64_t *tilekey_u64, int B, int H, int W,
-                           float *out, float *max_out, int32_t *argmax_i32);
+int fc3d_code_pattern_norm(void *stream, const float *raw, const uint64_t *tilekey_u64, int keys_per_image,
+                           int B, int H, int W, float *out, float *max_out, int32_t *argmax_i32);
 
 /* Backward w.r.t. pattern[...,0] (autograd of optics_pytorch.py:97-119).
  *   g_out [B][H][W] upstream gradient; out = the normalised forward result.   */
