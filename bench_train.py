@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Training steps/s of the full loop (capture simulation -> U-Nets -> losses incl. the
+re-projection loss -> backward -> RCCL gradient all-reduce -> Adam), data parallel.
+
+    python bench_train.py [--gpus N] [--steps K] [--warmup W] [--batch 32] [--size 512]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench_train.py --gpus N ...
+
+Batch is per GPU (weak scaling; the reference's configuration 3 is 32 per GPU on 8 GPUs = 256).
+Prints one json line on rank 0.  bench.py (image formation alone) is the headline benchmark;
+this one shows the same kernels inside a training step and the cost of the collective."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "depth-estimation_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--size", type=int, default=512)
+    args = ap.parse_args()
+    from fc3d import capture, dist as fdist, synth
+    import geometry_pytorch as G
+    import optics_pytorch as O
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    rank, world, _ = fdist.init_from_env("nccl", dev)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    H = W = args.size
+    sc = synth.make_scene(args.batch, H, W, fdist.shard_seed(3000, rank), pose_scale=min(1.0, W / 512))
+    O.PSFs_np = synth.make_psfs(21, 5, "disc")
+    K = np.diag([1666.67, 1666.67, 1, 1])
+    K[0][2], K[1][2] = W / 2, H / 2
+    Kb = torch.from_numpy(K).float().to(dev).unsqueeze(0).repeat(args.batch, 1, 1)
+    G.get_intrinsic = lambda B, device="cuda": Kb[:B]
+    d = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
+    z_p, z_c, pose = d(sc["z_p"]), d(sc["z_c"]), d(sc["pose_p2c"])
+    torch.manual_seed(1234)          # identical initial weights on every rank
+    step = capture.TrainStep(dev)
+    for _ in range(args.warmup):
+        step(z_p, z_c, pose)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step(z_p, z_c, pose)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    el = fdist.max_over_ranks(time.perf_counter() - t0, dev)
+    if rank == 0:
+        print(json.dumps({"metric": "training steps/sec (capture simulation + 2 U-Nets + reproj loss + Adam), data parallel",
+                          "value": args.steps / el, "unit": "steps/s", "samples_per_s": world * args.batch * args.steps / el,
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
+                          "scaling": "weak", "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": f"{args.batch}x{H}x{W} per GPU, global batch {world * args.batch}",
+                                     "grad_allreduce_bytes": step.bucket.nbytes}, "loss": float(loss)}), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

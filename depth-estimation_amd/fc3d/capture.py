@@ -1,0 +1,175 @@
+"""Host-side counterpart of the two callers of the image-formation path in the
+reference's training script: forward_model (train_pytorch.py:79-162) and
+reProj_IpGT (:179-211), plus the small loss / normalisation helpers they use
+(utils_pytorch.py:148-222, 251-301).  Everything heavy goes through the
+drop-in operators of optics_pytorch / geometry_pytorch (HIP kernels); the
+glue around them is stock tensor arithmetic.
+
+Unlike the reference these functions take the image size from their inputs
+(the reference hard-codes 800x1200 and a 512 centre crop), accept the pattern
+and the noise tensors as arguments (so runs are reproducible on any device),
+and build the ray table once per size instead of with a per-pixel Python loop.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+import geometry_pytorch as G
+import optics_pytorch as O
+
+from . import synth
+
+_consts: dict = {}
+
+
+def _rays_xy(H: int, W: int, device) -> torch.Tensor:
+    key = ("xy", H, W, str(device))
+    if key not in _consts:
+        ray = G.pixel_to_ray_array(W, H)[:, :, 0:2]
+        _consts[key] = torch.from_numpy(np.ascontiguousarray(ray)).float().to(device)
+    return _consts[key]
+
+
+def dot_pattern(H: int, W: int, device) -> torch.Tensor:
+    """[1,H,W,1] binary dot array ('dotArray' mode of utils_pytorch.py:85-137), cached per size."""
+    key = ("dots", H, W, str(device))
+    if key not in _consts:
+        _consts[key] = torch.from_numpy(synth.dot_pattern(H, W)).to(device).view(1, H, W, 1)
+    return _consts[key]
+
+
+def image_gradients(img):
+    """Forward differences padded with a zero last row / column; utils_pytorch.py:206-222."""
+    dy = F.pad(img[:, 1:] - img[:, :-1], (0, 0, 0, 0, 0, 1))
+    dx = F.pad(img[:, :, 1:] - img[:, :, :-1], (0, 0, 0, 1, 0, 0))
+    return dy, dx
+
+
+def with_reflectance(I, depth):
+    """I * (0.8 cos(atan(|grad z| / 100um)) + 0.2); utils_pytorch.py:251-280."""
+    dy, dx = image_gradients(depth)
+    theta = torch.atan(torch.sqrt(dy ** 2 + dx ** 2) / 100e-6)
+    return I * (torch.cos(theta) * 0.8 + 0.2)
+
+
+def local_norm(Im, kernelsize=17, constant=0.01):
+    """Im / (box mean + c); utils_pytorch.py:285-301."""
+    mean = F.avg_pool2d(Im.permute(0, 3, 1, 2), kernelsize, stride=1, padding=kernelsize // 2).permute(0, 2, 3, 1)
+    return Im / (mean + constant)
+
+
+def cost_rms_mask(GT, hat, mask, eps=1e-6):
+    return torch.sqrt(torch.sum(torch.square(mask * (GT - hat))) / torch.sum(mask).clamp(min=eps) + eps)
+
+
+def cost_L1_mask(GT, hat, mask):
+    return torch.sum(mask * torch.abs(GT - hat)) / (torch.sum(mask) + 1)
+
+
+def erode(mask, k):
+    """1 where the whole k x k neighbourhood is 1 (avg-pool > 0.999); train_pytorch.py:184-186."""
+    m = F.avg_pool2d(mask.permute(0, 3, 1, 2), kernel_size=k, stride=1, padding=k // 2).permute(0, 2, 3, 1)
+    return (m > 0.999).float()
+
+
+def cost_grad_mask(GT, hat, mask):
+    me = erode(mask, 9)
+    GTy, GTx = image_gradients(GT)
+    hy, hx = image_gradients(hat)
+    return cost_rms_mask(GTx, hx, me) + cost_rms_mask(GTy, hy, me)
+
+
+def centre_crop(t, N):
+    H, W = t.shape[1:3]
+    if N is None or (N >= H and N >= W):
+        return t
+    h0, w0 = (H - N) // 2, (W - N) // 2
+    return t[:, h0:h0 + N, w0:w0 + N, :]
+
+
+def forward_model(z_p, z_c, pose_p2c, n_layers=21, is_conv_psf=True, crop=None, noise=None, pattern=None):
+    """Simulated capture; train_pytorch.py:79-162.  noise: optional dict(offset [B,1,1,1] in
+    [0,1), gauss [B,H,W,1] ~ N(0,1), scale [B,1,1,1] in [0,1)); drawn on the device if absent."""
+    B, H, W, _ = z_p.shape
+    dev = z_p.device
+    rays = G.pixel_to_ray_array(W, H)
+    coord_p = G.points_in_camera_coords(z_p, rays).permute(0, 3, 1, 2)
+    coord_c = G.points_in_camera_coords(z_c, rays).permute(0, 3, 1, 2)
+    Ip = dot_pattern(H, W, dev) if pattern is None else pattern
+    Ip_ref = with_reflectance(Ip, z_p)
+    Ip_coded = O.codePattern(Ip_ref, z_p, is_conv_psf=is_conv_psf, n_layers=n_layers)
+    Ic, grid_p2c, grid_c2p = G.warp_p2c(Ip_coded, coord_p, coord_c, pose_p2c)
+    if noise is None:
+        noise = dict(offset=torch.rand(B, 1, 1, 1, device=dev), gauss=torch.randn(B, H, W, 1, device=dev),
+                     scale=torch.rand(B, 1, 1, 1, device=dev))
+    Ic_exp = Ic + noise["offset"] * 0.05 + noise["gauss"] * 0.005
+    Ic_max = Ic_exp.amax(dim=(1, 2), keepdim=True)
+    Ic_scaled = torch.clamp(Ic_exp / Ic_max * (noise["scale"] * 0.3 + 0.7), 0.0, 1.0)
+    vis = G.gen_visible_mask(grid_p2c, 'all')
+    xy = _rays_xy(H, W, dev).unsqueeze(0).expand(B, -1, -1, -1)
+    xyz_cView = G.bilinear_sampler(torch.cat([xy, z_p], dim=-1), grid_c2p) * vis
+    Ic_mask = (Ic_scaled > 0.05).float() * vis
+    c = lambda t: centre_crop(t, crop)  # noqa: E731
+    return (c(Ic_scaled), c(Ic_mask), c(xyz_cView), c(xy), c(z_c), c(z_p), pose_p2c, z_p, c(Ic), Ip_coded, Ic_scaled)
+
+
+def reProj_IpGT(zp_cView, pose_p2c, xy, Ic, zcGT, maskC, IpGT):
+    """Re-projection loss; train_pytorch.py:179-211 (one crop per sample)."""
+    me = erode(maskC, 5)
+    zp = zp_cView * me
+    zc = G.zp_cView_to_zc(zp, pose_p2c, xy)
+    ray = torch.cat([xy, torch.ones_like(zc)], dim=-1)
+    coord_c = G.points_in_camera_coords(zc, ray, allBatch=True).permute(0, 3, 1, 2)
+    # inverse(pose) once, through the library's own kernel, as a detached constant
+    from . import ops
+    _, _, pose_c2p = ops.pose_transforms(pose_p2c.detach(), None, want_a=True)
+    grid_c2p = G.coord0TOgrid1(coord_c, pose_c2p)
+    Ic_reProj = G.bilinear_sampler(IpGT, grid_c2p)
+    loss_zc_rms = cost_rms_mask(zcGT, zc, me)
+    loss_Ic_rms = cost_rms_mask(Ic, Ic_reProj, me)
+    loss_Ic_L1 = cost_L1_mask(Ic, Ic_reProj, me)
+    return loss_Ic_L1 + loss_zc_rms, loss_zc_rms, loss_Ic_rms, loss_Ic_L1
+
+
+def cal_cost(xyz, xyz_hat, mask):
+    """Reconstruction loss; train_pytorch.py:214-230."""
+    l_xy = cost_rms_mask(xyz[..., :2], xyz_hat[..., :2], mask)
+    l_z = cost_rms_mask(xyz[..., 2:3], xyz_hat[..., 2:3], mask)
+    l_g = cost_grad_mask(xyz[..., 2:3], xyz_hat[..., 2:3], erode(mask, 5))
+    return l_xy + l_z + l_g, l_xy, l_z, l_g
+
+
+class TrainStep:
+    """One optimisation step of the reference's loop (train_pytorch.py:283-304) on a
+    per-rank batch; gradients of the two U-Nets are averaged over ranks in one flat
+    all-reduce that is started right after backward."""
+
+    def __init__(self, device, n_layers=21, is_conv_psf=True, crop=None, lr=1e-4, weight_reproj=1.0):
+        from . import dist as fdist
+        from . import nets
+        self.model_xy = nets.UNet_xy().to(device)
+        self.model_z = nets.UNet_z().to(device)
+        self.params = list(self.model_xy.parameters()) + list(self.model_z.parameters())
+        self.bucket = fdist.FlatGradBucket(self.params)
+        self.opt = torch.optim.Adam(self.params, lr=lr)
+        self.n_layers, self.is_conv_psf, self.crop, self.w = n_layers, is_conv_psf, crop, weight_reproj
+
+    def __call__(self, z_p, z_c, pose_p2c, noise=None):
+        self.model_xy.train()
+        self.model_z.train()
+        with torch.no_grad():
+            (Ic_s, Ic_m, xyz, xy, zc, zp, pose, _zp_full, Ic, Ip_coded, _) = forward_model(
+                z_p, z_c, pose_p2c, self.n_layers, self.is_conv_psf, self.crop, noise)
+        inp = local_norm(Ic_s, 17, 0.01)
+        xyz_hat = torch.cat([self.model_xy(inp), self.model_z(inp)], dim=-1)
+        loss_recon, *_ = cal_cost(xyz, xyz_hat, Ic_m)
+        loss_reproj, *_ = reProj_IpGT(xyz_hat[..., 2:3], pose, xy, Ic, zc, Ic_m, Ip_coded)
+        loss = loss_recon + loss_reproj * self.w
+        self.bucket.zero()
+        loss.backward()
+        self.bucket.average(async_op=True)
+        self.bucket.wait()
+        self.opt.step()
+        return loss.detach()

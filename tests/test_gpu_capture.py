@@ -1,0 +1,100 @@
+"""The callers of the path (capture simulator, re-projection loss, one training step) on the GPU,
+against the same composition written with the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import geometry_pytorch as G
+    import optics_pytorch as O
+    from fc3d import capture, synth
+    import fc3d_oracle as orc
+    return dict(G=G, O=O, capture=capture, synth=synth, orc=orc)
+
+
+def K_fn(W, H):
+    def get_intrinsic(B, device="cuda"):
+        K = np.diag([1666.67, 1666.67, 1, 1])
+        K[0][2], K[1][2] = W / 2, H / 2
+        return torch.from_numpy(K).float().to(device).unsqueeze(0).repeat(B, 1, 1)
+    return get_intrinsic
+
+
+def test_forward_model_and_reproj_vs_oracle(env, monkeypatch):
+    G, O, capture, synth, orc = (env[k] for k in ("G", "O", "capture", "synth", "orc"))
+    B, H, W, L, N = 2, 96, 128, 21, 64
+    monkeypatch.setattr(G, "get_intrinsic", K_fn(W, H))
+    sc = synth.make_scene(B, H, W, 91)
+    psfs = synth.make_psfs(L, 5, "disc")
+    O.PSFs_np = psfs
+    rs = np.random.RandomState(92)
+    noise = dict(offset=rs.rand(B, 1, 1, 1).astype(np.float32), gauss=rs.randn(B, H, W, 1).astype(np.float32),
+                 scale=rs.rand(B, 1, 1, 1).astype(np.float32))
+    d = lambda a: torch.from_numpy(a).cuda()  # noqa: E731
+    t = torch.from_numpy
+    out = capture.forward_model(d(sc["z_p"]), d(sc["z_c"]), d(sc["pose_p2c"]), L, True, N,
+                                {k: d(v) for k, v in noise.items()})
+    Ic_s, Ic_m, xyz, xy, zc, zp, pose, zp_full, Ic, Ip_coded, Ic_s_full = out
+    assert Ic_s.shape == (B, N, N, 1) and xyz.shape == (B, N, N, 3) and Ip_coded.shape == (B, H, W, 1)
+
+    # the same composition with the oracle on the CPU
+    z_p, z_c, pose_c = t(sc["z_p"]), t(sc["z_c"]), t(sc["pose_p2c"])
+    Ip = t(synth.dot_pattern(H, W)).view(1, H, W, 1)
+    dy = F.pad(z_p[:, 1:] - z_p[:, :-1], (0, 0, 0, 0, 0, 1))
+    dx = F.pad(z_p[:, :, 1:] - z_p[:, :, :-1], (0, 0, 0, 1, 0, 0))
+    refl = torch.cos(torch.atan(torch.sqrt(dy ** 2 + dx ** 2) / 100e-6)) * 0.8 + 0.2
+    pat = (Ip * refl).expand(-1, -1, -1, L)
+    Ipc, Ic_r, gp, gc = orc.image_formation(pat, z_p, orc.z2pointcloud(z_p), orc.z2pointcloud(z_c), pose_c, psfs,
+                                            W / 2, H / 2)
+    Ie = Ic_r + t(noise["offset"]) * 0.05 + t(noise["gauss"]) * 0.005
+    Is = torch.clamp(Ie / Ie.amax(dim=(1, 2), keepdim=True) * (t(noise["scale"]) * 0.3 + 0.7), 0, 1)
+    vis = orc.gen_visible_mask(gp, "all")
+    xy_r = t(orc.pixel_to_ray_array(W, H)[:, :, :2]).float().unsqueeze(0).expand(B, -1, -1, -1)
+    xyz_r = orc.bilinear_sampler(torch.cat([xy_r, z_p], -1), gc) * vis
+    h0, w0 = (H - N) // 2, (W - N) // 2
+    crop = lambda a: a[:, h0:h0 + N, w0:w0 + N]  # noqa: E731
+    assert rel_err(Ip_coded.cpu().numpy(), Ipc.numpy()) < 1e-4
+    assert rel_err(Ic.cpu().numpy(), crop(Ic_r).numpy()) < 1e-4
+    assert rel_err(Ic_s.cpu().numpy(), crop(Is).numpy()) < 1e-4
+    assert rel_err(xyz.cpu().numpy(), crop(xyz_r).numpy()) < 1e-4
+    m_ref = crop((Is > 0.05).float() * vis).numpy()
+    assert (Ic_m.cpu().numpy() != m_ref).mean() < 1e-3        # threshold at 0.05 may flip on a rounding-level tie
+
+    # re-projection loss and its gradient w.r.t. the predicted depth
+    zhat = (zc + 0.003 * torch.randn_like(zc)).requires_grad_(True)
+    loss, l_zc, l_rms, l_l1 = capture.reProj_IpGT(zhat, pose, xy, Ic, zc, Ic_m, Ip_coded)
+    loss.backward()
+    zh = zhat.detach().cpu().requires_grad_(True)
+    me = (F.avg_pool2d(Ic_m.cpu().permute(0, 3, 1, 2), 5, 1, 2).permute(0, 2, 3, 1) > 0.999).float()
+    zc_r, grid_r, Ic_rp = orc.reproject_chain(zh * me, pose_c, xy.cpu(), Ip_coded.cpu(), W / 2, H / 2)
+    l1 = torch.sum(me * torch.abs(Ic.cpu() - Ic_rp)) / (me.sum() + 1)
+    lz = torch.sqrt(torch.sum(torch.square(me * (zc.cpu() - zc_r))) / me.sum().clamp(min=1e-6) + 1e-6)
+    (l1 + lz).backward()
+    assert abs(float(loss) - float(l1 + lz)) < 1e-4 * abs(float(l1 + lz))
+    assert rel_err(zhat.grad.cpu().numpy(), zh.grad.numpy()) < 2e-3      # L1 loss: sign flips at |diff|~0 pixels
+
+
+def test_train_step_runs(env, monkeypatch):
+    G, O, capture, synth = env["G"], env["O"], env["capture"], env["synth"]
+    B, H, W = 2, 64, 64
+    monkeypatch.setattr(G, "get_intrinsic", K_fn(W, H))
+    O.PSFs_np = synth.make_psfs(21, 5, "disc")
+    sc = synth.make_scene(B, H, W, 93)
+    d = lambda a: torch.from_numpy(a).cuda()  # noqa: E731
+    torch.manual_seed(0)
+    step = capture.TrainStep(torch.device("cuda"))
+    assert step.bucket.nbytes == 17271657 * 4
+    w0 = step.params[0].detach().clone()
+    losses = [float(step(d(sc["z_p"]), d(sc["z_c"]), d(sc["pose_p2c"]))) for _ in range(3)]
+    assert all(np.isfinite(losses)), losses
+    assert not torch.equal(w0, step.params[0].detach())               # the optimizer moved the weights
+    assert float(step.bucket.flat.abs().sum()) > 0

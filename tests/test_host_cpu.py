@@ -1,0 +1,152 @@
+"""CPU-only checks: the C ABI exports what include/fc3d.h declares, host-side logic of the
+drop-in modules, the U-Net restatement, and the data-parallel helpers under gloo (2 ranks)."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cabi_exports_every_declared_symbol():
+    from fc3d import _native
+    hdr = open(os.path.join(ROOT, "include", "fc3d.h")).read()
+    declared = set(re.findall(r"\b(fc3d_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    lib = _native.load()                       # loads without a GPU: no HIP call is made
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in fc3d.h but not exported"
+    assert declared == set(_native.SIGNATURES), declared ^ set(_native.SIGNATURES)
+    assert lib.fc3d_version() == 100
+    assert lib.fc3d_status_string(-1).decode().startswith("invalid")
+    # argument validation happens before any device work
+    assert lib.fc3d_visible_mask(None, None, 1, 4, 4, 0, None, None) == -1
+    assert lib.fc3d_code_pattern_fwd_workspace(32, 512, 512) == 32 * 256 * 8
+    assert lib.fc3d_bilinear_bwd_img_workspace(2, 64, 96, 1, 64, 96) == 2 * 24 * (16 + 1024 * 4)
+
+
+def test_layer_grid_matches_reference_tables(golden):
+    import optics_pytorch as O
+    g = golden("g1_layers")
+    z = g["z"].reshape(-1).astype(np.float32)
+    for L in (21, 41, 20, 5):
+        lg = O._layer_grid(L)
+        # the kernel's fp32 recipe, evaluated with numpy fp32 scalars
+        c, iz0, st, c0 = (np.float32(v) for v in (lg.coeff, lg.inv_z0, lg.step, lg.centre0))
+        r = (np.float32(1.0) / z).astype(np.float32)
+        wm = (c * (r - iz0).astype(np.float32)).astype(np.float32)
+        rr = np.rint((wm / st).astype(np.float32))
+        lf = np.rint((rr - c0).astype(np.float32))
+        ok = (lf >= 0) & (lf < L) & (np.abs(rr - (c0 + lf).astype(np.float32)) < np.float32(0.01))
+        lay = np.where(ok, lf, -1).astype(np.int16)
+        assert np.array_equal(lay, g[f"layer_L{L}"].reshape(-1)), L
+
+
+def test_dropin_module_surface(golden):
+    """Same public names / defaults as the reference modules (train_pytorch.py:23-29 imports)."""
+    import inspect
+    import geometry_pytorch as G
+    import optics_pytorch as O
+    for name in ("warp_p2c", "z2pointcloud", "bilinear_sampler", "gen_visible_mask", "coord0TOgrid1",
+                 "pixel_to_ray_array", "points_in_camera_coords", "zp_cView_to_zc", "coord_transform",
+                 "get_intrinsic", "pixel_to_ray"):
+        assert callable(getattr(G, name)), name
+    assert (G.H, G.W) == (800, 1200)
+    for name in ("codePattern", "codePattern_simple", "gen_WmMask", "z2Wm"):
+        assert callable(getattr(O, name)), name
+    assert (O.wvl, O.z_min, O.z_max, O.z0) == (530e-9, 0.695714566, 0.941062289, 0.8)
+    assert O.PSFs_np.shape == (21, 5, 5, 1) and O.fn_psfs == 'psfs_exp.npy'
+    sig = inspect.signature(O.codePattern)
+    assert list(sig.parameters)[:4] == ["pattern", "zMap", "device", "is_conv_psf"]
+    assert sig.parameters["device"].default == 'cuda' and sig.parameters["is_conv_psf"].default is True
+    assert inspect.signature(G.gen_visible_mask).parameters["method"].default == 'round'
+    assert list(inspect.signature(G.pixel_to_ray_array).parameters.values())[0].default == 1200
+    g0 = golden("g0_rays")
+    assert np.abs(G.pixel_to_ray_array(24, 10) - g0["rays_24x10"]).max() < 1e-15
+    assert G.pixel_to_ray_array() is G.pixel_to_ray_array()            # cached, not a 1 s python loop
+    assert np.abs(np.array([G.pixel_to_ray((0, 0)), G.pixel_to_ray((1199, 799)), G.pixel_to_ray((600, 400))])
+                  - g0["corner_rays"]).max() < 1e-15
+    assert np.array_equal(G.get_intrinsic(2, device='cpu').numpy(), g0["intrinsic"])
+    assert float(O.z2Wm(0.8)) == 0.0 and abs(float(O.z2Wm(O.z_min)) - 60) < 1e-6
+    g1 = golden("g1_layers")
+    assert np.array_equal(O.z2Wm(torch.from_numpy(g1["z"])).numpy(), g1["Wm"])
+    layers = np.linspace(O.z2Wm(O.z_max), O.z2Wm(O.z_min), 21)
+    m = O.gen_WmMask(torch.from_numpy(g1["Wm"]), layers, 'cpu')
+    idx = m.argmax(-1)
+    idx[m.sum(-1) == 0] = -1
+    assert np.array_equal(idx.numpy().astype(np.int16), g1["layer_L21"])
+    t = torch.rand(1, 4, 4, 3)
+    assert torch.equal(O.codePattern_simple(t, None), t[..., 0:1]) and O.codePattern_simple(t[..., :1], None) is not None
+    with pytest.raises(RuntimeError, match="GPU only"):
+        O.codePattern(torch.zeros(1, 8, 8, 21), torch.ones(1, 8, 8, 1))
+    with pytest.raises(UnboundLocalError):
+        G.gen_visible_mask(torch.zeros(1, 2, 2, 2), "nearest")
+
+
+def test_unets_match_reference_parameter_count():
+    from fc3d import nets
+    nxy = sum(p.numel() for p in nets.UNet_xy().parameters())
+    nz = sum(p.numel() for p in nets.UNet_z().parameters())
+    assert (nxy, nz) == (8635846, 8635811)                 # 17,271,657 in total, as the reference
+    net = nets.UNet_z().eval()
+    out = net(torch.rand(1, 32, 48, 1))
+    assert out.shape == (1, 32, 48, 1) and float(out.min()) >= nets.Z_MIN and float(out.max()) <= nets.Z_MAX
+    out = nets.UNet_xy().eval()(torch.rand(1, 32, 48, 1))
+    assert out.shape == (1, 32, 48, 2)
+
+
+def test_synthetic_scene_is_deterministic_and_in_range():
+    from fc3d import synth
+    a = synth.make_scene(2, 32, 48, 5)
+    b = synth.make_scene(2, 32, 48, 5)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    assert a["z_p"].min() >= synth.Z_MIN and a["z_p"].max() <= synth.Z_MAX
+    R = a["pose_p2c"][0, :3, :3].astype(np.float64)
+    assert np.abs(R @ R.T - np.eye(3)).max() < 1e-6
+    p = synth.make_psfs(21, 5, "disc")
+    assert p.shape == (21, 5, 5, 1) and np.allclose(p.sum(axis=(1, 2, 3)), 1, atol=1e-6)
+    d = synth.dot_pattern(64, 96)
+    assert set(np.unique(d)) == {0.0, 1.0} and 0.05 < d.mean() < 0.5
+
+
+_WORKER = r'''
+import os, sys, torch
+sys.path.insert(0, os.path.join(sys.argv[1], "depth-estimation_amd"))
+from fc3d import dist as fdist
+rank, world, local = fdist.init_from_env("gloo")
+assert world == 2
+torch.manual_seed(0)
+net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 1))
+bucket = fdist.FlatGradBucket(net.parameters())
+assert bucket.nbytes == 4 * sum(p.numel() for p in net.parameters())
+x = torch.arange(12.0).reshape(2, 6) * (rank + 1) / 10
+bucket.zero()
+net(x).sum().backward()
+local_grad = bucket.flat.clone()
+bucket.average(async_op=True); bucket.wait()
+# reference: gather every rank's local gradient and average by hand
+allg = [torch.zeros_like(local_grad) for _ in range(world)]
+torch.distributed.all_gather(allg, local_grad)
+assert torch.allclose(bucket.flat, sum(allg) / world, atol=1e-7)
+assert all(p.grad.data_ptr() >= bucket.flat.data_ptr() for p in net.parameters())   # still views of the bucket
+assert fdist.max_over_ranks(float(rank + 1)) == 2.0
+assert fdist.shard_seed(1000, rank) == 1000 + 100 * rank
+torch.distributed.barrier()
+torch.distributed.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_data_parallel_helpers_gloo_two_ranks(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29611", str(script), ROOT],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("ok") == 2
