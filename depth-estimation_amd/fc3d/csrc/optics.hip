@@ -446,11 +446,12 @@ __global__ __launch_bounds__(NT) void code_pattern_fwd_wide_kernel(
     unsigned long long* __restrict__ tilekey) {
     constexpr int KWP = Wide<KW>::KWP, NSEG = Wide<KW>::NSEG, HALO = Wide<KW>::HALO, RS = Wide<KW>::RS;
     extern __shared__ float smem[];
-    __shared__ int s_lmin, s_lmax;
+    __shared__ int s_lmin, s_lmax, s_qn;
     __shared__ unsigned long long s_key[NT / 64];
 
     const int b = blockIdx.z;
     const int x0 = blockIdx.x * WX, y0 = blockIdx.y * WY;
+    if (threadIdx.x == 0) s_qn = 0;
     const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
     const int x = x0 + 4 * tx;
     const long img = (long)b * H * W;
@@ -529,6 +530,78 @@ __global__ __launch_bounds__(NT) void code_pattern_fwd_wide_kernel(
     __syncthreads();
 
     float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if (stage_all) {
+        // A wavefront's 256-pixel row crosses several depth layers, but a lane's 4 x 2 pixels almost
+        // always share one.  Every lane blurs all its pixels with the PSF of its first valid pixel's
+        // layer (PSF rows in registers, no per-pixel branches); the few pixels of another layer are
+        // queued in LDS and redone one per thread afterwards.  Both passes add taps in the same
+        // order (dy, then dx ascending), so a pixel's value does not depend on the pass that made it.
+        uint32_t* q = reinterpret_cast<uint32_t*>(wts + lg.n_layers * Kh * KWP);
+        int lp = -1, cnt = 0;
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (lp < 0 && lay[o][i] >= 0) lp = lay[o][i];
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cnt += (lay[o][i] >= 0 && lay[o][i] != lp) ? 1 : 0;
+        int slot = 0;
+        if (cnt) {
+            slot = atomicAdd(&s_qn, cnt);
+            int j = 0;
+#pragma unroll
+            for (int o = 0; o < 2; ++o)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (lay[o][i] >= 0 && lay[o][i] != lp)
+                        q[slot + j++] = ((uint32_t)(2 * ty + o) << 16) | ((uint32_t)(4 * tx + i) << 8) | (uint32_t)lay[o][i];
+        }
+        if (lp >= 0) {
+            const float* wl = wts + lp * Kh * KWP;
+            // input row rr of the lane's 2-row strip feeds output row 0 with dy = rr, row 1 with dy = rr-1
+            for (int rr = 0; rr <= Kh; ++rr) {
+                float seg[4 * NSEG];
+                lds_read4<4 * NSEG>(tile + (2 * ty + rr) * RS + 4 * tx, seg);
+#pragma unroll
+                for (int o = 0; o < 2; ++o) {
+                    const int dy = rr - o;
+                    if (dy < 0 || dy >= Kh) continue;
+                    float w[KWP];
+                    lds_read4<KWP>(wl + dy * KWP, w);
+#pragma unroll
+                    for (int dx = 0; dx < KW; ++dx)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[o][i] = fmaf(w[dx], seg[dx + i], acc[o][i]);
+                }
+            }
+        }
+        __syncthreads();
+        const int qn = s_qn;
+        for (int e = tid; e < qn; e += NT) {
+            const uint32_t v = q[e];
+            const int row = (int)(v >> 16), col = (int)((v >> 8) & 255u), l = (int)(v & 255u);
+            const float* wl = wts + l * Kh * KWP;
+            float a = 0.0f;
+            for (int dy = 0; dy < Kh; ++dy) {
+                const float* tr = tile + (row + dy) * RS + col;
+                const float* wr = wl + dy * KWP;
+#pragma unroll
+                for (int dx = 0; dx < KW; ++dx) a = fmaf(wr[dx], tr[dx], a);
+            }
+            q[e] = __float_as_uint(a);
+        }
+        __syncthreads();
+        if (cnt) {
+            int j = 0;
+#pragma unroll
+            for (int o = 0; o < 2; ++o)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (lay[o][i] >= 0 && lay[o][i] != lp) acc[o][i] = __uint_as_float(q[slot + j++]);
+        }
+    } else {
     bool uni[2], any[2];
 #pragma unroll
     for (int o = 0; o < 2; ++o) {
@@ -569,6 +642,8 @@ __global__ __launch_bounds__(NT) void code_pattern_fwd_wide_kernel(
                 }
             }
         }
+    }
+
     }
 
     // -- gate by the layer mask (a multiply, so a non-finite blur still poisons the pixel as conv*0
@@ -746,6 +821,7 @@ __global__ __launch_bounds__(NT) void code_pattern_bwd_wide_kernel(
             }
         }
     }
+    
 #pragma unroll
     for (int o = 0; o < 2; ++o) {
         const int y = y0 + 2 * ty + o;
@@ -774,7 +850,10 @@ static size_t wide_lds_plan(int Kh, int L, bool bwd, int* stage_all, int* cap) {
     if (c > L) c = L;
     *stage_all = (c == L) && ((size_t)L * per_layer <= 16 * 1024);
     *cap = (int)c;
-    return tile_b + (size_t)c * per_layer;
+    // With every layer staged the forward kernel keeps a 2048-entry redo queue behind the weights.
+    // (The same scheme was tried for the backward kernel and lost: there an output must be redone
+    // whenever ANY source of its K x K footprint lies in another layer, ~40% of them: 103 vs 74 us.)
+    return tile_b + (size_t)c * per_layer + ((*stage_all && !bwd) ? (size_t)WX * WY * 4 : 0);
 }
 
 template <typename K>
