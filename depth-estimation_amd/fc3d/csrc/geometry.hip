@@ -435,14 +435,23 @@ __device__ __forceinline__ void load_tile_taps(const float* __restrict__ g_out, 
     }
 }
 
-// win[cell] += val for every active lane; lanes aiming at the same cell take turns.
+// win[cell] += val for every active lane; lanes aiming at the same cell take turns.  The common
+// case (no two lanes of this instruction share a cell) is straight-line code: elect, add, one
+// vote; only a collision enters the retry loop.
 __device__ __forceinline__ void window_add(volatile float* win, volatile uint8_t* own, int cell, float val,
                                            bool active, int lane) {
     bool pend = active;
-    while (__ballot(pend)) {
+    if (pend) {
+        own[cell] = (uint8_t)lane;
+        if (own[cell] == (uint8_t)lane) {          // LDS runs a wavefront's ds ops in order: this reads the winner
+            win[cell] = win[cell] + val;
+            pend = false;
+        }
+    }
+    while (__builtin_expect(__ballot(pend) != 0, 0)) {
         if (pend) {
             own[cell] = (uint8_t)lane;
-            if (own[cell] == (uint8_t)lane) {      // LDS runs a wavefront's ds ops in order: this reads the winner
+            if (own[cell] == (uint8_t)lane) {
                 win[cell] = win[cell] + val;
                 pend = false;
             }

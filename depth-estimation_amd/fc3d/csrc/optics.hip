@@ -809,13 +809,22 @@ __global__ __launch_bounds__(NT) void code_pattern_bwd_wide_kernel(
                 for (int e = 0; e < KW + 3; ++e) {
                     const int l = (int)((lw[e >> 2] >> (8 * (e & 3))) & 0xffu);
                     if (l == 255) continue;
-                    const bool in_lds = (l >= bl0) && (l - bl0 < nl);
-                    const float* wr =
-                        in_lds ? (wts + ((l - bl0) * Kh + dy) * KWP) : (psf + ((long)l * Kh + dy) * KW);
+                    // two explicit branches: one pointer that may be LDS or global would compile to
+                    // flat loads, which crawl through the vector-memory path even for LDS addresses
+                    if (stage_all || ((l >= bl0) && (l - bl0 < nl))) {
+                        const float* wr = wts + ((l - bl0) * Kh + dy) * KWP;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int ee = e - i;
-                        if (ee >= 0 && ee < KW) acc[o][i] = fmaf(wr[KW - 1 - ee], seg[e], acc[o][i]);
+                        for (int i = 0; i < 4; ++i) {
+                            const int ee = e - i;
+                            if (ee >= 0 && ee < KW) acc[o][i] = fmaf(wr[KW - 1 - ee], seg[e], acc[o][i]);
+                        }
+                    } else {
+                        const float* wr = psf + ((long)l * Kh + dy) * KW;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int ee = e - i;
+                            if (ee >= 0 && ee < KW) acc[o][i] = fmaf(wr[KW - 1 - ee], seg[e], acc[o][i]);
+                        }
                     }
                 }
             }
