@@ -846,6 +846,128 @@ __global__ __launch_bounds__(NT) void code_pattern_bwd_wide_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Rolling-row kernels for small odd square PSFs (3x3, 5x5, 7x7).
+//
+// A wavefront owns a strip 64 lanes wide (one pixel column per lane) and walks down R output
+// rows.  Neighbouring columns are reached with wavefront shifts (DPP), not through LDS, so the
+// strips overlap by K-1 columns and only the inner 64-(K-1) lanes store results.  LDS holds
+// nothing but the PSF stack; there is no barrier after the prologue.
+//
+// Backward (scatter form): source pixel p = (y, x) of layer l adds PSF[l][dy][dx] * graw[p] to
+// output (y + dy - pad, x + dx - pad).  Each lane keeps the K*K weights of its own pixel's layer
+// in registers (reloaded from LDS only on rows where some lane's layer differs from the row
+// above), forms its K products for one PSF row and passes them sideways Horner fashion: one
+// shift per column step, K-1 shifts per PSF row.  Output rows live in rolling accumulators.
+// ---------------------------------------------------------------------------------------
+template <int K>
+struct Roll {
+    static constexpr int PAD = (K - 1) / 2;
+    static constexpr int SW = 64 - (K - 1);      // output columns per strip
+    static constexpr int KK = K * K;
+    static constexpr int KKP = (KK + 3) & ~3;    // one layer's PSF, padded to whole float4s
+};
+
+// lane i receives lane i-1's value (lane 0: zero) / lane i+1's value (lane 63: zero)
+__device__ __forceinline__ float from_lane_below(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));   // wave_shr:1
+}
+__device__ __forceinline__ float from_lane_above(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));   // wave_shl:1
+}
+
+template <int K>
+__device__ __forceinline__ void stage_psf_stack(float* __restrict__ wts, const float* __restrict__ psf, int L) {
+    constexpr int KK = Roll<K>::KK, KKP = Roll<K>::KKP;
+    for (int i = threadIdx.x; i < L * KKP; i += NT) {
+        const int l = i / KKP, j = i - l * KKP;
+        wts[i] = j < KK ? psf[l * KK + j] : 0.0f;
+    }
+}
+
+template <int K, int R>
+__global__ __launch_bounds__(NT) void code_pattern_bwd_roll_kernel(
+    const float* __restrict__ g, const uint8_t* __restrict__ layer_u8, const float* __restrict__ max_in,
+    const int* __restrict__ argmax_in, const float* __restrict__ partial, int npartial,
+    const float* __restrict__ psf, int H, int W, int L, float* __restrict__ g_pat0) {
+    constexpr int PAD = Roll<K>::PAD, SW = Roll<K>::SW, KKP = Roll<K>::KKP;
+    constexpr int NR = R + K - 1;                 // source rows a strip reads
+    extern __shared__ float smem[];               // [L][KKP]
+    __shared__ float s_red[NT / 64];
+    const int b = blockIdx.z;
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    const long img = (long)b * H * W;
+
+    float s = 0.0f;
+    for (int i = tid; i < npartial; i += NT) s += partial[(long)b * npartial + i];
+    const float S = block_sum(s, s_red);
+    const float den = max_in[b] + 1e-10f;
+    const float rden = 1.0f / den;
+    const float corr = S / den;                   // d/d(max) of sum(g * raw/den) = -sum(g*out)/den
+    const int am = argmax_in[b];
+    stage_psf_stack<K>(smem, psf, L);
+    __syncthreads();
+
+    const int xs = (blockIdx.x * (NT / 64) + wv) * SW;   // first output column of this wavefront's strip
+    if (xs >= W) return;
+    const int x = xs - PAD + lane;
+    const int y0 = blockIdx.y * R;
+    const bool colok = x >= 0 && x < W;
+    const int xc = min(max(x, 0), W - 1);
+    const float* gi = g + img;
+    const uint8_t* li = layer_u8 + img;
+
+    // every source row up front, from clamped (always valid) addresses: one memory latency per strip
+    float gv[NR];
+    int lv[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int yc = min(max(y0 - PAD + r, 0), H - 1);
+        gv[r] = gi[yc * W + xc];
+        lv[r] = li[yc * W + xc];
+    }
+
+    float w[KKP];
+    int lcur = 0;
+    lds_read4<KKP>(smem, w);
+    float acc[R];
+#pragma unroll
+    for (int o = 0; o < R; ++o) acc[o] = 0.0f;
+
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int y = y0 - PAD + r;
+        const bool ok = colok && y >= 0 && y < H && lv[r] != 255;
+        float v = ok ? gv[r] * rden : 0.0f;
+        v -= (ok && y * W + x == am) ? corr : 0.0f;
+        const int l = ok ? lv[r] : lcur;          // pixels that contribute nothing keep the weights they have
+        if (__ballot(l != lcur) != 0ull) {
+            lds_read4<KKP>(smem + l * KKP, w);
+            lcur = l;
+        }
+#pragma unroll
+        for (int dy = 0; dy < K; ++dy) {
+            const int o = r + dy - 2 * PAD;       // output row (from y0) fed by source row r through PSF row dy
+            if (o < 0 || o >= R) continue;
+            const float* wr = w + dy * K;
+            float up = wr[K - 1] * v;             // travels to higher lanes
+#pragma unroll
+            for (int dx = K - 2; dx > PAD; --dx) up = fmaf(wr[dx], v, from_lane_below(up));
+            up = from_lane_below(up);
+            float dn = wr[0] * v;                 // travels to lower lanes
+#pragma unroll
+            for (int dx = 1; dx < PAD; ++dx) dn = fmaf(wr[dx], v, from_lane_above(dn));
+            dn = from_lane_above(dn);
+            acc[o] = (fmaf(wr[PAD], v, acc[o]) + up) + dn;
+        }
+        if (r >= 2 * PAD) {
+            const int o = r - 2 * PAD;            // complete: its last source row was this one
+            const int yo = y0 + o;
+            if (lane >= PAD && lane < 64 - PAD && x < W && yo < H) g_pat0[img + (long)yo * W + x] = acc[o];
+        }
+    }
+}
+
 // LDS plan of the wide kernels: returns bytes (0 = does not fit), and through the pointers whether
 // all L layers are staged (no per-tile layer range needed) and how many layers the weight area holds.
 constexpr int kWideLdsBudget = 96 * 1024;
@@ -981,6 +1103,20 @@ extern "C" int fc3d_code_pattern_bwd(void* stream, const float* g_out, const flo
     auto kr = rvec ? code_pattern_bwd_reduce_kernel<true> : code_pattern_bwd_reduce_kernel<false>;
     FC3D_LAUNCH("code_pattern_bwd_reduce", kr, dim3(nred, B), dim3(NT), 0, s, g_out, out, HW, partial);
     const bool vec = (W % 4 == 0) && aligned16(g_pat0);
+    if (conv_flag && Kh == Kw) {
+        constexpr int R = 16;
+#define FC3D_BWD_ROLL_CASE(KV)                                                                                   \
+    if (Kw == KV) {                                                                                              \
+        const size_t rlds = (size_t)L * Roll<KV>::KKP * sizeof(float);                                           \
+        if (int e = allow_big_lds(code_pattern_bwd_roll_kernel<KV, R>, rlds)) return e;                          \
+        FC3D_LAUNCH("code_pattern_bwd", (code_pattern_bwd_roll_kernel<KV, R>),                                   \
+                    dim3(cdiv(cdiv(W, Roll<KV>::SW), NT / 64), cdiv(H, R), B), dim3(NT), rlds, s, g_out,         \
+                    layer_u8, max_in, argmax_i32, (const float*)partial, nred, psf, H, W, L, g_pat0);            \
+        return FC3D_OK;                                                                                          \
+    }
+        FC3D_BWD_ROLL_CASE(3) FC3D_BWD_ROLL_CASE(5) FC3D_BWD_ROLL_CASE(7)
+#undef FC3D_BWD_ROLL_CASE
+    }
     if (conv_flag && W >= 192) {
         int stage_all = 0, fcap = 0;
         size_t flds = 0;

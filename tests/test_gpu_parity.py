@@ -111,7 +111,8 @@ def test_code_pattern_vs_oracle_ragged(mods):
     O, synth, orc = mods["O"], mods["synth"], mods["orc"]
     rs = np.random.RandomState(5)
     for (B, H, W, L, K, kind) in ((1, 19, 37, 21, 5, "rand"), (2, 33, 70, 41, 8, "rand"), (1, 70, 130, 41, 23, "disc"),
-                                  (1, 17, 66, 21, 33, "gauss"), (3, 16, 64, 21, 1, "rand")):
+                                  (1, 17, 66, 21, 33, "gauss"), (3, 16, 64, 21, 1, "rand"), (2, 40, 100, 21, 3, "rand"),
+                                  (1, 50, 130, 41, 7, "gauss"), (1, 35, 61, 21, 5, "disc"), (1, 3, 2, 21, 7, "rand")):
         z = rs.uniform(0.69, 0.95, (B, H, W, 1)).astype(np.float32)
         p0 = rs.uniform(0, 1, (B, H, W, 1)).astype(np.float32)
         gg = rs.uniform(-1, 1, (B, H, W, 1)).astype(np.float32)
