@@ -459,9 +459,32 @@ __device__ __forceinline__ void window_add(volatile float* win, volatile uint8_t
     }
 }
 
+// The four taps of one sample: a sample that is kept has x1 = x0 + 1 and y1 = y0 + 1, so its cells
+// are c, c+1, c+ww, c+ww+1, and lanes with distinct base cells c have distinct cells in each of
+// the four add instructions.  One election on c therefore covers all four; the adds themselves
+// stay separate instructions in program order because lane i's c+1 may be lane j's c.
+__device__ __forceinline__ void window_add4(volatile float* win, volatile uint8_t* own, int c, int ww, float v00,
+                                            float v10, float v01, float v11, bool active, int lane) {
+    bool pend = active;
+    do {
+        if (pend) {
+            own[c] = (uint8_t)lane;
+            if (own[c] == (uint8_t)lane) {
+                win[c] = win[c] + v00;
+                win[c + 1] = win[c + 1] + v10;
+                win[c + ww] = win[c + ww] + v01;
+                win[c + ww + 1] = win[c + ww + 1] + v11;
+                pend = false;
+            }
+        }
+    } while (__builtin_expect(__ballot(pend) != 0, 0));
+}
+
+template <bool DIRECT>
 __global__ __launch_bounds__(NT) void bilinear_bwd_img_scatter_kernel(
     const float* __restrict__ g_out, const float* __restrict__ grid, const uint8_t* __restrict__ mask_u8, int Hs,
-    int Ws, int Ht, int Wt, int tiles_x, int ntiles, TileMeta* __restrict__ meta, float* __restrict__ slab) {
+    int Ws, int Ht, int Wt, int tiles_x, int ntiles, TileMeta* __restrict__ meta, float* __restrict__ slab,
+    float* __restrict__ g_img) {
     __shared__ float s_win[NT / 64][WIN_CAP];
     __shared__ uint8_t s_own[NT / 64][WIN_CAP];
     const int b = blockIdx.y;
@@ -492,13 +515,32 @@ __global__ __launch_bounds__(NT) void bilinear_bwd_img_scatter_kernel(
         for (int k = 0; k < 4; ++k) {
             const Taps& tp = px[k].t;
             const bool on = px[k].on;
-            const int r0 = on ? (tp.y0 - ymin) * ww : 0, r1 = on ? (tp.y1 - ymin) * ww : 0;
-            const int c0 = on ? tp.x0 - xmin : 0, c1 = on ? tp.x1 - xmin : 0;
-            window_add(w, own, r0 + c0, (tp.wx0 * tp.wy0) * px[k].v, on, lane);
-            window_add(w, own, r1 + c0, (tp.wx0 * tp.wy1) * px[k].v, on, lane);
-            window_add(w, own, r0 + c1, (tp.wx1 * tp.wy0) * px[k].v, on, lane);
-            window_add(w, own, r1 + c1, (tp.wx1 * tp.wy1) * px[k].v, on, lane);
+            const int c00 = on ? (tp.y0 - ymin) * ww + (tp.x0 - xmin) : 0;
+            window_add4(w, own, c00, ww, (tp.wx0 * tp.wy0) * px[k].v, (tp.wx1 * tp.wy0) * px[k].v,
+                        (tp.wx0 * tp.wy1) * px[k].v, (tp.wx1 * tp.wy1) * px[k].v, on, lane);
         }
+    }
+    if (DIRECT) {
+        float* o = g_img + (long)b * Hs * Ws;
+        if (n > 0) {
+            o += (long)ymin * Ws + xmin;
+            for (int r = 0; r < wh; ++r)
+                for (int c = lane; c < ww; c += 64) {
+                    const float v = w[r * ww + c];
+                    if (v != 0.0f) atomicAdd(o + (long)r * Ws + c, v);
+                }
+        } else if (!empty) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (px[k].on) {
+                    const Taps& tp = px[k].t;
+                    atomicAdd(o + (long)tp.y0 * Ws + tp.x0, (tp.wx0 * tp.wy0) * px[k].v);
+                    atomicAdd(o + (long)tp.y1 * Ws + tp.x0, (tp.wx0 * tp.wy1) * px[k].v);
+                    atomicAdd(o + (long)tp.y0 * Ws + tp.x1, (tp.wx1 * tp.wy0) * px[k].v);
+                    atomicAdd(o + (long)tp.y1 * Ws + tp.x1, (tp.wx1 * tp.wy1) * px[k].v);
+                }
+        }
+        return;
     }
     const long tg = (long)b * ntiles + t;
     float* s = slab + tg * WIN_CAP;
@@ -902,8 +944,14 @@ extern "C" int fc3d_bilinear_bwd_img(void* stream, const float* g_out, const flo
     TileMeta* meta = (TileMeta*)workspace;
     float* slab = (float*)(meta + (size_t)B * ntiles);
     const dim3 gs(cdiv(ntiles, NT / 64), B), blk(NT);
-    FC3D_LAUNCH("bilinear_bwd_img_scatter", bilinear_bwd_img_scatter_kernel, gs, blk, 0, s, g_out, grid, mask_u8, Hs, Ws, Ht, Wt, tiles_x,
-                       ntiles, meta, slab);
+    if (getenv("FC3D_WARP_ATOMIC")) {
+        FC3D_HIP(hipMemsetAsync(g_img, 0, (size_t)B * Hs * Ws * sizeof(float), s));
+        FC3D_LAUNCH("bilinear_bwd_img_scatter", bilinear_bwd_img_scatter_kernel<true>, gs, blk, 0, s, g_out, grid, mask_u8, Hs, Ws, Ht, Wt, tiles_x,
+                       ntiles, meta, slab, g_img);
+        return FC3D_OK;
+    }
+    FC3D_LAUNCH("bilinear_bwd_img_scatter", bilinear_bwd_img_scatter_kernel<false>, gs, blk, 0, s, g_out, grid, mask_u8, Hs, Ws, Ht, Wt, tiles_x,
+                       ntiles, meta, slab, g_img);
     FC3D_LAUNCH_CHECK();
     FC3D_LAUNCH("bilinear_bwd_img_merge", bilinear_bwd_img_merge_kernel, dim3(cdiv(Ws, MT_X), cdiv(Hs, MT_Y), B), blk, 0, s,
                        (const TileMeta*)meta, (const float*)slab, ntiles, Hs, Ws, g_img);

@@ -968,6 +968,90 @@ __global__ __launch_bounds__(NT) void code_pattern_bwd_roll_kernel(
     }
 }
 
+// Forward (gather form): every arriving pattern row is spread into its K column neighbours with
+// K-1 shifts and kept for K rows; a finished output row takes K*K fused multiply-adds with the
+// weights of its own pixel's layer (dy, then dx ascending, like the other forward kernels).
+// One max key per wavefront strip goes to the normalisation pass.
+template <int K, int R>
+__global__ __launch_bounds__(NT) void code_pattern_fwd_roll_kernel(
+    const float* __restrict__ pat0, long sb, long sh, long sw, const float* __restrict__ z,
+    const float* __restrict__ psf, int H, int W, fc3d_layer_grid lg, float* __restrict__ raw,
+    uint8_t* __restrict__ layer_u8, unsigned long long* __restrict__ tilekey) {
+    constexpr int PAD = Roll<K>::PAD, SW = Roll<K>::SW, KKP = Roll<K>::KKP;
+    constexpr int NR = R + K - 1;
+    extern __shared__ float smem[];               // [L][KKP]
+    const int b = blockIdx.z;
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    const long img = (long)b * H * W;
+    stage_psf_stack<K>(smem, psf, lg.n_layers);
+    __syncthreads();
+
+    const int strip = blockIdx.x * (NT / 64) + wv;
+    const long kidx = ((long)b * gridDim.y + blockIdx.y) * (gridDim.x * (NT / 64)) + strip;
+    const int xs = strip * SW;
+    if (xs >= W) {
+        if (lane == 0) tilekey[kidx] = 0ull;      // below every real key
+        return;
+    }
+    const int x = xs - PAD + lane;
+    const int y0 = blockIdx.y * R;
+    const bool colok = x >= 0 && x < W;
+    const bool mine = lane >= PAD && lane < 64 - PAD && x < W;   // columns this lane writes
+    const int xc = min(max(x, 0), W - 1);
+    const float* pimg = pat0 + (long)b * sb + (long)xc * sw;
+    const float* zimg = z + img + xc;
+
+    float pv[NR], zv[R];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) pv[r] = pimg[(long)min(max(y0 - PAD + r, 0), H - 1) * sh];
+#pragma unroll
+    for (int o = 0; o < R; ++o) zv[o] = zimg[min(y0 + o, H - 1) * W];
+
+    float w[KKP];
+    int lcur = 0;
+    lds_read4<KKP>(smem, w);
+    float win[NR][K];
+    unsigned long long key = 0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int y = y0 - PAD + r;
+        win[r][PAD] = (colok && y >= 0 && y < H) ? pv[r] : 0.0f;     // zero 'same' padding
+#pragma unroll
+        for (int d = 1; d <= PAD; ++d) {
+            win[r][PAD - d] = from_lane_below(win[r][PAD - d + 1]);
+            win[r][PAD + d] = from_lane_above(win[r][PAD + d - 1]);
+        }
+        if (r >= K - 1) {
+            const int o = r - (K - 1);
+            const int yo = y0 + o;
+            const bool inb = mine && yo < H;
+            const int l = inb ? layer_of(zv[o], lg) : -1;
+            const int lw = l >= 0 ? l : lcur;
+            if (__ballot(lw != lcur) != 0ull) {
+                lds_read4<KKP>(smem + lw * KKP, w);
+                lcur = lw;
+            }
+            float a = 0.0f;
+#pragma unroll
+            for (int dy = 0; dy < K; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < K; ++dx) a = fmaf(w[dy * K + dx], win[o + dy][dx], a);
+            a = a * (l >= 0 ? 1.0f : 0.0f);       // a multiply: a non-finite blur still poisons the pixel
+            if (inb) {
+                const uint32_t pos = 0xffffffffu - (uint32_t)(x * H + yo);   // first w, then first h
+                const unsigned long long k = ((unsigned long long)float_to_key(a) << 32) | pos;
+                key = k > key ? k : key;
+                raw[img + (long)yo * W + x] = a;
+                if (layer_u8) layer_u8[img + (long)yo * W + x] = (uint8_t)l;
+            }
+        }
+    }
+    key = wave_max(key);
+    if (lane == 0) tilekey[kidx] = key;
+}
+
+constexpr int kRollRows = 16;                     // output rows per strip of the rolling-row kernels
+
 // LDS plan of the wide kernels: returns bytes (0 = does not fit), and through the pointers whether
 // all L layers are staged (no per-tile layer range needed) and how many layers the weight area holds.
 constexpr int kWideLdsBudget = 96 * 1024;
@@ -1015,7 +1099,9 @@ using namespace fc3d;
 extern "C" size_t fc3d_code_pattern_fwd_workspace(int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0) return 0;
     const long a = (long)cdiv(W, TX) * cdiv(H, TY), w = (long)cdiv(W, WX) * cdiv(H, WY);
-    return (size_t)B * (a > w ? a : w) * sizeof(unsigned long long);
+    const long r = (long)cdiv(cdiv(W, Roll<7>::SW), NT / 64) * (NT / 64) * cdiv(H, 8);
+    const long m = a > w ? (a > r ? a : r) : (w > r ? w : r);
+    return (size_t)B * m * sizeof(unsigned long long);
 }
 
 extern "C" size_t fc3d_code_pattern_bwd_workspace(int B, int H, int W) {
@@ -1043,6 +1129,25 @@ extern "C" int fc3d_code_pattern_fwd(void* stream, const float* pat0, int64_t pa
                      (!layer_u8 || aligned4(layer_u8));
     dim3 g(cdiv(W, TX), cdiv(H, TY), B), blk(NT);
     hipStream_t s = (hipStream_t)stream;
+    if (conv_flag && Kh == Kw) {
+#define FC3D_FWD_ROLL_CASE(KV)                                                                                   \
+    if (Kw == KV) {                                                                                              \
+        const size_t rlds = (size_t)grid.n_layers * Roll<KV>::KKP * sizeof(float);                               \
+        if (int e = allow_big_lds(code_pattern_fwd_roll_kernel<KV, RR>, rlds)) return e;                  \
+        const dim3 gr(cdiv(cdiv(W, Roll<KV>::SW), NT / 64), cdiv(H, RR), B);                              \
+        *keys_per_image = (int)(gr.x * (NT / 64) * gr.y);                                                        \
+        FC3D_LAUNCH("code_pattern_fwd", (code_pattern_fwd_roll_kernel<KV, RR>), gr, blk, rlds, s, pat0,   \
+                    (long)pat_sb, (long)pat_sh, (long)pat_sw, z, psf, H, W, grid, raw_out, layer_u8,             \
+                    (unsigned long long*)tilekey_u64);                                                           \
+        return FC3D_OK;                                                                                          \
+    }
+        const char* ev = getenv("FC3D_RF"); int rr = ev ? atoi(ev) : 16;
+        if (rr == 8) { constexpr int RR = 8; FC3D_FWD_ROLL_CASE(5) }
+        if (rr == 32) { constexpr int RR = 32; FC3D_FWD_ROLL_CASE(5) }
+        constexpr int RR = 16;
+        FC3D_FWD_ROLL_CASE(3) FC3D_FWD_ROLL_CASE(5) FC3D_FWD_ROLL_CASE(7)
+#undef FC3D_FWD_ROLL_CASE
+    }
     if (conv_flag && W >= 192) {
         int stage_all = 0, fcap = 0;
         size_t flds = 0;
@@ -1104,7 +1209,6 @@ extern "C" int fc3d_code_pattern_bwd(void* stream, const float* g_out, const flo
     FC3D_LAUNCH("code_pattern_bwd_reduce", kr, dim3(nred, B), dim3(NT), 0, s, g_out, out, HW, partial);
     const bool vec = (W % 4 == 0) && aligned16(g_pat0);
     if (conv_flag && Kh == Kw) {
-        constexpr int R = 16;
 #define FC3D_BWD_ROLL_CASE(KV)                                                                                   \
     if (Kw == KV) {                                                                                              \
         const size_t rlds = (size_t)L * Roll<KV>::KKP * sizeof(float);                                           \
@@ -1114,6 +1218,10 @@ extern "C" int fc3d_code_pattern_bwd(void* stream, const float* g_out, const flo
                     layer_u8, max_in, argmax_i32, (const float*)partial, nred, psf, H, W, L, g_pat0);            \
         return FC3D_OK;                                                                                          \
     }
+        const char* ev = getenv("FC3D_RB"); int rr = ev ? atoi(ev) : 16;
+        if (rr == 8) { constexpr int R = 8; FC3D_BWD_ROLL_CASE(5) }
+        if (rr == 32) { constexpr int R = 32; FC3D_BWD_ROLL_CASE(5) }
+        constexpr int R = 16;
         FC3D_BWD_ROLL_CASE(3) FC3D_BWD_ROLL_CASE(5) FC3D_BWD_ROLL_CASE(7)
 #undef FC3D_BWD_ROLL_CASE
     }
