@@ -41,11 +41,12 @@ ALG_BYTES = {
     "pose_transforms": 0,
     "warp_project_splat": 24,         # coord_p 16 -> grid_p2c 8 (mask is internal)
     "warp_sample": 32,                # Ip 4 + coord_c 16 -> Ic 4 + grid_c2p 8
-    "bilinear_bwd_img_scatter": 12,   # dL/dIc 4 + grid_c2p 8
-    "bilinear_bwd_img_merge": 4,      # -> dL/dIp 4
+    "bilinear_bwd_img_scatter": 16,   # dL/dIc 4 + grid_c2p 8 -> dL/dIp 4 (window sums added with atomics)
+    "bilinear_bwd_img_merge": 0,      # only in torch's deterministic mode (fixed-order merge of stored windows)
     "bilinear_bwd_img_overflow": 0,
-    "code_pattern_bwd_reduce": 0,     # second read of dL/dIp and Ip_coded: overhead
+    "code_pattern_bwd_reduce": 0,     # only for PSF sizes without a rolling-row kernel
     "code_pattern_bwd": 16,           # dL/dIp 4 + layer(z) 4 + Ip_coded 4 -> dL/dpattern0 4
+    "code_pattern_bwd_max": 0,        # footprint of the per-image maximum: K*K pixels per image
 }
 assert sum(ALG_BYTES.values()) == 100
 

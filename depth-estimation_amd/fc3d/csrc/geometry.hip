@@ -524,11 +524,13 @@ __global__ __launch_bounds__(NT) void bilinear_bwd_img_scatter_kernel(
         float* o = g_img + (long)b * Hs * Ws;
         if (n > 0) {
             o += (long)ymin * Ws + xmin;
-            for (int r = 0; r < wh; ++r)
-                for (int c = lane; c < ww; c += 64) {
-                    const float v = w[r * ww + c];
-                    if (v != 0.0f) atomicAdd(o + (long)r * Ws + c, v);
-                }
+            const unsigned magic = ((1u << 20) + (unsigned)ww - 1u) / (unsigned)ww;   // i / ww == (i * magic) >> 20 while i * ww < 2^20
+            for (int i = lane; i < n; i += 64) {
+                const float v = w[i];
+                const int r = (int)(((unsigned)i * magic) >> 20);
+                const int c = i - r * ww;
+                if (v != 0.0f) atomicAdd(o + (long)r * Ws + c, v);
+            }
         } else if (!empty) {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -938,18 +940,18 @@ extern "C" int fc3d_bilinear_bwd_img(void* stream, const float* g_out, const flo
         FC3D_LAUNCH_CHECK();
         return FC3D_OK;
     }
-    if (!workspace || !aligned16(workspace)) return workspace ? FC3D_EALIGN : FC3D_EINVAL;
     int tiles_x;
     const int ntiles = wave_tiles(Ht, Wt, &tiles_x);
-    TileMeta* meta = (TileMeta*)workspace;
-    float* slab = (float*)(meta + (size_t)B * ntiles);
     const dim3 gs(cdiv(ntiles, NT / 64), B), blk(NT);
-    if (getenv("FC3D_WARP_ATOMIC")) {
+    if (!workspace) {   // window sums go straight into the zeroed gradient image with float atomics
         FC3D_HIP(hipMemsetAsync(g_img, 0, (size_t)B * Hs * Ws * sizeof(float), s));
         FC3D_LAUNCH("bilinear_bwd_img_scatter", bilinear_bwd_img_scatter_kernel<true>, gs, blk, 0, s, g_out, grid, mask_u8, Hs, Ws, Ht, Wt, tiles_x,
-                       ntiles, meta, slab, g_img);
+                       ntiles, (TileMeta*)nullptr, (float*)nullptr, g_img);
         return FC3D_OK;
     }
+    if (!aligned16(workspace)) return FC3D_EALIGN;
+    TileMeta* meta = (TileMeta*)workspace;
+    float* slab = (float*)(meta + (size_t)B * ntiles);
     FC3D_LAUNCH("bilinear_bwd_img_scatter", bilinear_bwd_img_scatter_kernel<false>, gs, blk, 0, s, g_out, grid, mask_u8, Hs, Ws, Ht, Wt, tiles_x,
                        ntiles, meta, slab, g_img);
     FC3D_LAUNCH_CHECK();

@@ -234,6 +234,7 @@ __global__ __launch_bounds__(NT) void code_pattern_norm_kernel(
     const unsigned long long key = block_max_key(tilekey + (long)b * ntiles, ntiles, s_red);
     const float m = key_to_float((uint32_t)(key >> 32));
     const float den = m + 1e-10f;
+    const float rden = 1.0f / den;      // one rounding more than raw / den: far inside the fp tolerance
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const uint32_t pos = 0xffffffffu - (uint32_t)(key & 0xffffffffu);
         max_out[b] = m;
@@ -245,13 +246,13 @@ __global__ __launch_bounds__(NT) void code_pattern_norm_kernel(
         const long i = ((long)blockIdx.x * NT + threadIdx.x) * 4;
         if (i < HW) {
             float4 v = *reinterpret_cast<const float4*>(raw + base + i);
-            v.x = v.x / den; v.y = v.y / den; v.z = v.z / den; v.w = v.w / den;
+            v.x = v.x * rden; v.y = v.y * rden; v.z = v.z * rden; v.w = v.w * rden;
             *reinterpret_cast<float4*>(out + base + i) = v;
         }
     } else {
         const long i0 = ((long)blockIdx.x * NT + threadIdx.x) * 4;
         for (int k = 0; k < 4; ++k)
-            if (i0 + k < HW) out[base + i0 + k] = raw[base + i0 + k] / den;
+            if (i0 + k < HW) out[base + i0 + k] = raw[base + i0 + k] * rden;
     }
 }
 
@@ -885,31 +886,36 @@ __device__ __forceinline__ void stage_psf_stack(float* __restrict__ wts, const f
     }
 }
 
+//
+// The gradient that reaches the per-image maximum (-sum(g*out)/den, added to the one pixel that
+// holds the maximum) is not known before g and out have been read once.  Each strip therefore
+// also sums g*out over the pixels it owns into one partial per wavefront, and a follow-up kernel
+// (one workgroup per image) adds the partials in a fixed order and applies the K x K footprint
+// of that single pixel.  This saves a separate pass over g and out.
 template <int K, int R>
 __global__ __launch_bounds__(NT) void code_pattern_bwd_roll_kernel(
-    const float* __restrict__ g, const uint8_t* __restrict__ layer_u8, const float* __restrict__ max_in,
-    const int* __restrict__ argmax_in, const float* __restrict__ partial, int npartial,
-    const float* __restrict__ psf, int H, int W, int L, float* __restrict__ g_pat0) {
+    const float* __restrict__ g, const float* __restrict__ out, const uint8_t* __restrict__ layer_u8,
+    const float* __restrict__ max_in, const float* __restrict__ psf, int H, int W, int L,
+    float* __restrict__ partial, float* __restrict__ g_pat0) {
     constexpr int PAD = Roll<K>::PAD, SW = Roll<K>::SW, KKP = Roll<K>::KKP;
     constexpr int NR = R + K - 1;                 // source rows a strip reads
     extern __shared__ float smem[];               // [L][KKP]
-    __shared__ float s_red[NT / 64];
     const int b = blockIdx.z;
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const long img = (long)b * H * W;
 
-    float s = 0.0f;
-    for (int i = tid; i < npartial; i += NT) s += partial[(long)b * npartial + i];
-    const float S = block_sum(s, s_red);
     const float den = max_in[b] + 1e-10f;
     const float rden = 1.0f / den;
-    const float corr = S / den;                   // d/d(max) of sum(g * raw/den) = -sum(g*out)/den
-    const int am = argmax_in[b];
     stage_psf_stack<K>(smem, psf, L);
     __syncthreads();
 
-    const int xs = (blockIdx.x * (NT / 64) + wv) * SW;   // first output column of this wavefront's strip
-    if (xs >= W) return;
+    const int strip = blockIdx.x * (NT / 64) + wv;
+    const long pidx = ((long)b * gridDim.y + blockIdx.y) * (gridDim.x * (NT / 64)) + strip;
+    const int xs = strip * SW;                    // first output column of this wavefront's strip
+    if (xs >= W) {
+        if (lane == 0) partial[pidx] = 0.0f;
+        return;
+    }
     const int x = xs - PAD + lane;
     const int y0 = blockIdx.y * R;
     const bool colok = x >= 0 && x < W;
@@ -918,7 +924,7 @@ __global__ __launch_bounds__(NT) void code_pattern_bwd_roll_kernel(
     const uint8_t* li = layer_u8 + img;
 
     // every source row up front, from clamped (always valid) addresses: one memory latency per strip
-    float gv[NR];
+    float gv[NR], ov[R];
     int lv[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
@@ -926,6 +932,14 @@ __global__ __launch_bounds__(NT) void code_pattern_bwd_roll_kernel(
         gv[r] = gi[yc * W + xc];
         lv[r] = li[yc * W + xc];
     }
+#pragma unroll
+    for (int o = 0; o < R; ++o) ov[o] = out[img + min(y0 + o, H - 1) * W + xc];
+    const bool mine = lane >= PAD && lane < 64 - PAD && x < W;   // columns this lane writes
+    float sgo = 0.0f;
+#pragma unroll
+    for (int o = 0; o < R; ++o) sgo = fmaf((mine && y0 + o < H) ? gv[o + PAD] : 0.0f, ov[o], sgo);
+    sgo = wave_sum(sgo);
+    if (lane == 0) partial[pidx] = sgo;
 
     float w[KKP];
     int lcur = 0;
@@ -938,8 +952,7 @@ __global__ __launch_bounds__(NT) void code_pattern_bwd_roll_kernel(
     for (int r = 0; r < NR; ++r) {
         const int y = y0 - PAD + r;
         const bool ok = colok && y >= 0 && y < H && lv[r] != 255;
-        float v = ok ? gv[r] * rden : 0.0f;
-        v -= (ok && y * W + x == am) ? corr : 0.0f;
+        const float v = ok ? gv[r] * rden : 0.0f;
         const int l = ok ? lv[r] : lcur;          // pixels that contribute nothing keep the weights they have
         if (__ballot(l != lcur) != 0ull) {
             lds_read4<KKP>(smem + l * KKP, w);
@@ -963,7 +976,34 @@ __global__ __launch_bounds__(NT) void code_pattern_bwd_roll_kernel(
         if (r >= 2 * PAD) {
             const int o = r - 2 * PAD;            // complete: its last source row was this one
             const int yo = y0 + o;
-            if (lane >= PAD && lane < 64 - PAD && x < W && yo < H) g_pat0[img + (long)yo * W + x] = acc[o];
+            if (mine && yo < H) g_pat0[img + (long)yo * W + x] = acc[o];
+        }
+    }
+}
+
+// One workgroup per image, after the kernel above: S = sum of the partials (fixed order), then the
+// footprint of the maximum's pixel p: g_pat0[p + d - pad] -= S/den * PSF[layer(p)][d].
+__global__ __launch_bounds__(NT) void code_pattern_bwd_max_kernel(
+    const float* __restrict__ partial, int npartial, const float* __restrict__ max_in,
+    const int* __restrict__ argmax_in, const uint8_t* __restrict__ layer_u8, const float* __restrict__ psf, int H,
+    int W, int K, float* __restrict__ g_pat0) {
+    __shared__ float s_red[NT / 64];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float s = 0.0f;
+    for (int i = tid; i < npartial; i += NT) s += partial[(long)b * npartial + i];
+    const float S = block_sum(s, s_red);
+    const float corr = S / (max_in[b] + 1e-10f);
+    const int am = argmax_in[b];
+    const long img = (long)b * H * W;
+    const int l = layer_u8[img + am];
+    if (l == 255) return;                         // the maximum sits on a masked pixel (all-zero image): no gradient path
+    const int py = am / W, px = am - py * W, pad = (K - 1) / 2;
+    for (int d = tid; d < K * K; d += NT) {
+        const int dy = d / K, dx = d - dy * K;
+        const int qy = py + dy - pad, qx = px + dx - pad;
+        if (qy >= 0 && qy < H && qx >= 0 && qx < W) {
+            float* q = g_pat0 + img + (long)qy * W + qx;
+            *q = *q - corr * psf[(long)l * K * K + d];
         }
     }
 }
@@ -1050,7 +1090,7 @@ __global__ __launch_bounds__(NT) void code_pattern_fwd_roll_kernel(
     if (lane == 0) tilekey[kidx] = key;
 }
 
-constexpr int kRollRows = 16;                     // output rows per strip of the rolling-row kernels
+constexpr int kRollRows = 8;                      // output rows per strip of the rolling-row kernels
 
 // LDS plan of the wide kernels: returns bytes (0 = does not fit), and through the pointers whether
 // all L layers are staged (no per-tile layer range needed) and how many layers the weight area holds.
@@ -1099,14 +1139,16 @@ using namespace fc3d;
 extern "C" size_t fc3d_code_pattern_fwd_workspace(int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0) return 0;
     const long a = (long)cdiv(W, TX) * cdiv(H, TY), w = (long)cdiv(W, WX) * cdiv(H, WY);
-    const long r = (long)cdiv(cdiv(W, Roll<7>::SW), NT / 64) * (NT / 64) * cdiv(H, 8);
+    const long r = (long)cdiv(cdiv(W, Roll<7>::SW), NT / 64) * (NT / 64) * cdiv(H, kRollRows);
     const long m = a > w ? (a > r ? a : r) : (w > r ? w : r);
     return (size_t)B * m * sizeof(unsigned long long);
 }
 
 extern "C" size_t fc3d_code_pattern_bwd_workspace(int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0) return 0;
-    return (size_t)B * cdiv((long)H * W, RED_PX) * sizeof(float);
+    const long a = cdiv((long)H * W, RED_PX);
+    const long r = (long)cdiv(cdiv(W, Roll<7>::SW), NT / 64) * (NT / 64) * cdiv(H, kRollRows);
+    return (size_t)B * (a > r ? a : r) * sizeof(float);
 }
 
 extern "C" int fc3d_code_pattern_fwd(void* stream, const float* pat0, int64_t pat_sb, int64_t pat_sh,
@@ -1141,10 +1183,7 @@ extern "C" int fc3d_code_pattern_fwd(void* stream, const float* pat0, int64_t pa
                     (unsigned long long*)tilekey_u64);                                                           \
         return FC3D_OK;                                                                                          \
     }
-        const char* ev = getenv("FC3D_RF"); int rr = ev ? atoi(ev) : 16;
-        if (rr == 8) { constexpr int RR = 8; FC3D_FWD_ROLL_CASE(5) }
-        if (rr == 32) { constexpr int RR = 32; FC3D_FWD_ROLL_CASE(5) }
-        constexpr int RR = 16;
+        constexpr int RR = kRollRows;
         FC3D_FWD_ROLL_CASE(3) FC3D_FWD_ROLL_CASE(5) FC3D_FWD_ROLL_CASE(7)
 #undef FC3D_FWD_ROLL_CASE
     }
@@ -1204,27 +1243,27 @@ extern "C" int fc3d_code_pattern_bwd(void* stream, const float* g_out, const flo
     const long HW = (long)H * W;
     const int nred = cdiv(HW, RED_PX);
     float* partial = (float*)workspace;
-    const bool rvec = (HW % 4 == 0) && aligned16(g_out) && aligned16(out);
-    auto kr = rvec ? code_pattern_bwd_reduce_kernel<true> : code_pattern_bwd_reduce_kernel<false>;
-    FC3D_LAUNCH("code_pattern_bwd_reduce", kr, dim3(nred, B), dim3(NT), 0, s, g_out, out, HW, partial);
-    const bool vec = (W % 4 == 0) && aligned16(g_pat0);
     if (conv_flag && Kh == Kw) {
+        constexpr int R = kRollRows;
 #define FC3D_BWD_ROLL_CASE(KV)                                                                                   \
     if (Kw == KV) {                                                                                              \
         const size_t rlds = (size_t)L * Roll<KV>::KKP * sizeof(float);                                           \
         if (int e = allow_big_lds(code_pattern_bwd_roll_kernel<KV, R>, rlds)) return e;                          \
-        FC3D_LAUNCH("code_pattern_bwd", (code_pattern_bwd_roll_kernel<KV, R>),                                   \
-                    dim3(cdiv(cdiv(W, Roll<KV>::SW), NT / 64), cdiv(H, R), B), dim3(NT), rlds, s, g_out,         \
-                    layer_u8, max_in, argmax_i32, (const float*)partial, nred, psf, H, W, L, g_pat0);            \
+        const dim3 gr(cdiv(cdiv(W, Roll<KV>::SW), NT / 64), cdiv(H, R), B);                                      \
+        FC3D_LAUNCH("code_pattern_bwd", (code_pattern_bwd_roll_kernel<KV, R>), gr, dim3(NT), rlds, s, g_out,     \
+                    out, layer_u8, max_in, psf, H, W, L, partial, g_pat0);                                       \
+        FC3D_LAUNCH("code_pattern_bwd_max", code_pattern_bwd_max_kernel, dim3(B), dim3(NT), 0, s,                \
+                    (const float*)partial, (int)(gr.x * (NT / 64) * gr.y), max_in, argmax_i32, layer_u8, psf, H, \
+                    W, KV, g_pat0);                                                                              \
         return FC3D_OK;                                                                                          \
     }
-        const char* ev = getenv("FC3D_RB"); int rr = ev ? atoi(ev) : 16;
-        if (rr == 8) { constexpr int R = 8; FC3D_BWD_ROLL_CASE(5) }
-        if (rr == 32) { constexpr int R = 32; FC3D_BWD_ROLL_CASE(5) }
-        constexpr int R = 16;
         FC3D_BWD_ROLL_CASE(3) FC3D_BWD_ROLL_CASE(5) FC3D_BWD_ROLL_CASE(7)
 #undef FC3D_BWD_ROLL_CASE
     }
+    const bool rvec = (HW % 4 == 0) && aligned16(g_out) && aligned16(out);
+    auto kr = rvec ? code_pattern_bwd_reduce_kernel<true> : code_pattern_bwd_reduce_kernel<false>;
+    FC3D_LAUNCH("code_pattern_bwd_reduce", kr, dim3(nred, B), dim3(NT), 0, s, g_out, out, HW, partial);
+    const bool vec = (W % 4 == 0) && aligned16(g_pat0);
     if (conv_flag && W >= 192) {
         int stage_all = 0, fcap = 0;
         size_t flds = 0;

@@ -193,13 +193,18 @@ class ProjectFn(torch.autograd.Function):
 
 def _bilinear_bwd_img(g, grid, mask, B, Hs, Ws, C, Ht, Wt):
     dev = g.device
-    nbytes = _lib.fc3d_bilinear_bwd_img_workspace(B, Hs, Ws, C, Ht, Wt)
-    ws = torch.empty(max(16, nbytes) // 4, dtype=torch.float32, device=dev)
+    # torch.use_deterministic_algorithms(True) selects the fixed-order merge (needs a workspace);
+    # otherwise the per-wavefront sums are accumulated with float atomics, which is faster
+    ws = None
+    if C == 1 and torch.are_deterministic_algorithms_enabled():
+        nbytes = _lib.fc3d_bilinear_bwd_img_workspace(B, Hs, Ws, C, Ht, Wt)
+        ws = torch.empty(max(16, nbytes) // 4, dtype=torch.float32, device=dev)
     gi = torch.empty((B, Hs, Ws, C), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         _check(_lib.fc3d_bilinear_bwd_img(_stream(), g.data_ptr(), grid.data_ptr(),
                                           mask.data_ptr() if mask is not None else None, B, Hs, Ws, C, Ht, Wt,
-                                          ws.data_ptr(), gi.data_ptr()), "fc3d_bilinear_bwd_img")
+                                          ws.data_ptr() if ws is not None else None, gi.data_ptr()),
+               "fc3d_bilinear_bwd_img")
     return gi
 
 

@@ -131,8 +131,13 @@ int fc3d_bilinear_bwd_grid(void *stream, const float *g_out, const float *img, c
                            float *g_grid);
 
 /* d out / d img (scatter-add of the four weighted taps), written -- not
- * accumulated -- to g_img [B][Hs][Ws][C].  C == 1 is deterministic and free of
- * global atomics (per-wavefront LDS windows merged in a fixed order).         */
+ * accumulated -- to g_img [B][Hs][Ws][C].  For C == 1 every wavefront first sums
+ * its samples in a private LDS window.  workspace == NULL: the windows are added
+ * to g_img with float atomics (fastest; last-bit differences from run to run,
+ * like the reference's index_put/scatter backward on a GPU).  workspace of
+ * fc3d_bilinear_bwd_img_workspace() bytes: the windows are stored and merged in
+ * a fixed order, bit-reproducible and free of global atomics.  C != 1 ignores
+ * the workspace and uses atomics.                                             */
 size_t fc3d_bilinear_bwd_img_workspace(int B, int Hs, int Ws, int C, int Ht, int Wt);
 int fc3d_bilinear_bwd_img(void *stream, const float *g_out, const float *grid, const uint8_t *mask_u8,
                           int B, int Hs, int Ws, int C, int Ht, int Wt, void *workspace, float *g_img);

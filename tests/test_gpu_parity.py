@@ -210,14 +210,21 @@ def test_points_and_z2pointcloud(mods, golden):
     assert np.array_equal(G.get_intrinsic(2).cpu().numpy(), g0["intrinsic"])
 
 
-def test_bilinear_golden(mods, golden):
+@pytest.mark.parametrize("deterministic", [False, True])
+def test_bilinear_golden(mods, golden, deterministic):
+    """Both image-gradient paths: float-atomic accumulation (default) and the fixed-order merge
+    that torch.use_deterministic_algorithms(True) selects."""
     g = golden("g4_bilinear")
     G = mods["G"]
     for tag in "abc":
         img = dev(g[f"{tag}_img"]).requires_grad_(True)
         co = dev(g[f"{tag}_coords"]).requires_grad_(True)
         out = G.bilinear_sampler(img, co)
-        out.backward(dev(g[f"{tag}_g"]))
+        torch.use_deterministic_algorithms(deterministic, warn_only=True)
+        try:
+            out.backward(dev(g[f"{tag}_g"]))
+        finally:
+            torch.use_deterministic_algorithms(False)
         same = np.array_equal(out.detach().cpu().numpy(), g[f"{tag}_out"])
         assert same, tag
         # A sample a million pixels outside the image adds +-1e12-sized taps that cancel on one
