@@ -32,6 +32,40 @@ __device__ __forceinline__ int layer_of(float z, const fc3d_layer_grid& g) {
     return ok ? (int)lf : -1;
 }
 
+// layer_of with the two true divisions replaced by v_rcp_f32 and a multiplication by 1/step,
+// plus a flag that says when the shortcut could have changed the result.  With n the exact
+// chain's quotient and n' the shortcut's, |n' - n| <= eps * (|coeff/step| * |1/z| * 1.5 + 3|n|)
+// (eps = 2^-23: one ulp of the reciprocal, carried through the subtraction, and the roundings of
+// the two products); the layer depends on n only through rint(n), so whenever n' is further
+// than that bound from every half-integer both chains round to the same integer.  The bound is
+// evaluated, with a fourfold margin, for the largest |n| and |1/z| a pixel with an in-range
+// layer can have; pixels flagged ambiguous (a few in 10^4) are redone with layer_of.  Out-of-range,
+// infinite and NaN depths come out as -1 on both chains.
+struct LayerFast {
+    float rstep, thr;
+};
+__device__ __forceinline__ LayerFast layer_fast_setup(const fc3d_layer_grid& g) {
+    const float eps = 1.1920929e-7f;
+    const float nmax = fabsf(g.centre0) + (float)g.n_layers + 2.0f;
+    const float gain = fabsf(g.coeff / g.step);
+    const float rmax = fabsf(g.inv_z0) + nmax / gain;
+    LayerFast f;
+    f.rstep = 1.0f / g.step;
+    f.thr = 4.0f * eps * (1.5f * gain * rmax + 3.0f * nmax);   // NaN/inf for a degenerate grid: everything is redone exactly
+    return f;
+}
+__device__ __forceinline__ int layer_fast(float z, const fc3d_layer_grid& g, const LayerFast& f, bool& ambiguous) {
+    const float r = __builtin_amdgcn_rcpf(z);
+    const float d = r - g.inv_z0;
+    const float wm = g.coeff * d;
+    const float n = wm * f.rstep;
+    const float rr = rintf(n);
+    ambiguous = !(fabsf(n - rr) <= 0.5f - f.thr) && (fabsf(n) < 1.0e9f);
+    const float lf = rintf(rr - g.centre0);
+    const bool ok = (lf >= 0.0f) && (lf < (float)g.n_layers) && (fabsf(rr - (g.centre0 + lf)) < 0.01f);
+    return ok ? (int)lf : -1;
+}
+
 struct TileGeom {
     int th, tw, S;   // staged rows, staged columns, LDS row stride (floats)
 };
@@ -225,12 +259,26 @@ __device__ __forceinline__ unsigned long long block_max_key(const unsigned long 
     return k;
 }
 
+constexpr int NORM_V = 4;   // float4s per thread of the normalisation pass
+
 template <bool VEC>
 __global__ __launch_bounds__(NT) void code_pattern_norm_kernel(
     const float* __restrict__ raw, const unsigned long long* __restrict__ tilekey, int ntiles, int H, int W,
     float* __restrict__ out, float* __restrict__ max_out, int* __restrict__ argmax_out) {
     __shared__ unsigned long long s_red[NT / 64];
     const int b = blockIdx.y;
+    const long HW = (long)H * W;
+    const long base = (long)b * HW;
+    // the image data is requested before the key reduction so that the two latencies overlap
+    float4 v[NORM_V];
+    if (VEC) {
+#pragma unroll
+        for (int j = 0; j < NORM_V; ++j) {
+            const long i = (((long)blockIdx.x * NORM_V + j) * NT + threadIdx.x) * 4;
+            v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < HW) v[j] = *reinterpret_cast<const float4*>(raw + base + i);
+        }
+    }
     const unsigned long long key = block_max_key(tilekey + (long)b * ntiles, ntiles, s_red);
     const float m = key_to_float((uint32_t)(key >> 32));
     const float den = m + 1e-10f;
@@ -240,19 +288,18 @@ __global__ __launch_bounds__(NT) void code_pattern_norm_kernel(
         max_out[b] = m;
         argmax_out[b] = (int)(pos % (uint32_t)H) * W + (int)(pos / (uint32_t)H);
     }
-    const long HW = (long)H * W;
-    const long base = (long)b * HW;
     if (VEC) {
-        const long i = ((long)blockIdx.x * NT + threadIdx.x) * 4;
-        if (i < HW) {
-            float4 v = *reinterpret_cast<const float4*>(raw + base + i);
-            v.x = v.x * rden; v.y = v.y * rden; v.z = v.z * rden; v.w = v.w * rden;
-            *reinterpret_cast<float4*>(out + base + i) = v;
+#pragma unroll
+        for (int j = 0; j < NORM_V; ++j) {
+            const long i = (((long)blockIdx.x * NORM_V + j) * NT + threadIdx.x) * 4;
+            if (i < HW)
+                *reinterpret_cast<float4*>(out + base + i) =
+                    make_float4(v[j].x * rden, v[j].y * rden, v[j].z * rden, v[j].w * rden);
         }
     } else {
-        const long i0 = ((long)blockIdx.x * NT + threadIdx.x) * 4;
-        for (int k = 0; k < 4; ++k)
-            if (i0 + k < HW) out[base + i0 + k] = raw[base + i0 + k] * rden;
+        const long i0 = (long)blockIdx.x * NORM_V * NT * 4;
+        for (long i = i0 + threadIdx.x; i < i0 + (long)NORM_V * NT * 4 && i < HW; i += NT)
+            out[base + i] = raw[base + i] * rden;
     }
 }
 
@@ -869,6 +916,17 @@ struct Roll {
     static constexpr int KKP = (KK + 3) & ~3;    // one layer's PSF, padded to whole float4s
 };
 
+// Uniform 64-bit base + 32-bit per-lane *byte* offset: the form the global load/store
+// instructions take directly (scalar base register pair + one offset VGPR), no 64-bit lane math.
+template <typename T>
+__device__ __forceinline__ T ld_at(const T* base, unsigned elem) {
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + elem * (unsigned)sizeof(T));
+}
+template <typename T>
+__device__ __forceinline__ void st_at(T* base, unsigned elem, T v) {
+    *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + elem * (unsigned)sizeof(T)) = v;
+}
+
 // lane i receives lane i-1's value (lane 0: zero) / lane i+1's value (lane 63: zero)
 __device__ __forceinline__ float from_lane_below(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));   // wave_shr:1
@@ -904,36 +962,38 @@ __global__ __launch_bounds__(NT) void code_pattern_bwd_roll_kernel(
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const long img = (long)b * H * W;
 
-    const float den = max_in[b] + 1e-10f;
-    const float rden = 1.0f / den;
-    stage_psf_stack<K>(smem, psf, L);
-    __syncthreads();
-
     const int strip = blockIdx.x * (NT / 64) + wv;
     const long pidx = ((long)b * gridDim.y + blockIdx.y) * (gridDim.x * (NT / 64)) + strip;
     const int xs = strip * SW;                    // first output column of this wavefront's strip
-    if (xs >= W) {
-        if (lane == 0) partial[pidx] = 0.0f;
-        return;
-    }
     const int x = xs - PAD + lane;
     const int y0 = blockIdx.y * R;
     const bool colok = x >= 0 && x < W;
     const int xc = min(max(x, 0), W - 1);
-    const float* gi = g + img;
+    const float* gi = g + img;              // uniform 64-bit bases + 32-bit per-lane offsets
     const uint8_t* li = layer_u8 + img;
+    const float* oi = out + img;
+    float* gp = g_pat0 + img;
 
-    // every source row up front, from clamped (always valid) addresses: one memory latency per strip
+    // every source row up front, from clamped (always valid) addresses, and before the PSF stack
+    // is staged: one memory latency per strip, overlapped with the staging
     float gv[NR], ov[R];
     int lv[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
-        const int yc = min(max(y0 - PAD + r, 0), H - 1);
-        gv[r] = gi[yc * W + xc];
-        lv[r] = li[yc * W + xc];
+        const unsigned q = (unsigned)(min(max(y0 - PAD + r, 0), H - 1) * W + xc);
+        gv[r] = ld_at(gi, q);
+        lv[r] = ld_at(li, q);
     }
 #pragma unroll
-    for (int o = 0; o < R; ++o) ov[o] = out[img + min(y0 + o, H - 1) * W + xc];
+    for (int o = 0; o < R; ++o) ov[o] = ld_at(oi, (unsigned)(min(y0 + o, H - 1) * W + xc));
+    const float den = max_in[b] + 1e-10f;
+    const float rden = 1.0f / den;
+    stage_psf_stack<K>(smem, psf, L);
+    __syncthreads();
+    if (xs >= W) {
+        if (lane == 0) partial[pidx] = 0.0f;
+        return;
+    }
     const bool mine = lane >= PAD && lane < 64 - PAD && x < W;   // columns this lane writes
     float sgo = 0.0f;
 #pragma unroll
@@ -976,7 +1036,7 @@ __global__ __launch_bounds__(NT) void code_pattern_bwd_roll_kernel(
         if (r >= 2 * PAD) {
             const int o = r - 2 * PAD;            // complete: its last source row was this one
             const int yo = y0 + o;
-            if (mine && yo < H) g_pat0[img + (long)yo * W + x] = acc[o];
+            if (mine && yo < H) st_at(gp, (unsigned)(yo * W + x), acc[o]);
         }
     }
 }
@@ -1012,8 +1072,10 @@ __global__ __launch_bounds__(NT) void code_pattern_bwd_max_kernel(
 // K-1 shifts and kept for K rows; a finished output row takes K*K fused multiply-adds with the
 // weights of its own pixel's layer (dy, then dx ascending, like the other forward kernels).
 // One max key per wavefront strip goes to the normalisation pass.
+// (six wavefronts per SIMD: the kernel waits on memory more than it computes, and two more
+// resident wavefronts are worth the couple of spilled registers the limit costs)
 template <int K, int R>
-__global__ __launch_bounds__(NT) void code_pattern_fwd_roll_kernel(
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6))) void code_pattern_fwd_roll_kernel(
     const float* __restrict__ pat0, long sb, long sh, long sw, const float* __restrict__ z,
     const float* __restrict__ psf, int H, int W, fc3d_layer_grid lg, float* __restrict__ raw,
     uint8_t* __restrict__ layer_u8, unsigned long long* __restrict__ tilekey) {
@@ -1023,29 +1085,33 @@ __global__ __launch_bounds__(NT) void code_pattern_fwd_roll_kernel(
     const int b = blockIdx.z;
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const long img = (long)b * H * W;
-    stage_psf_stack<K>(smem, psf, lg.n_layers);
-    __syncthreads();
-
     const int strip = blockIdx.x * (NT / 64) + wv;
     const long kidx = ((long)b * gridDim.y + blockIdx.y) * (gridDim.x * (NT / 64)) + strip;
     const int xs = strip * SW;
-    if (xs >= W) {
-        if (lane == 0) tilekey[kidx] = 0ull;      // below every real key
-        return;
-    }
     const int x = xs - PAD + lane;
     const int y0 = blockIdx.y * R;
     const bool colok = x >= 0 && x < W;
     const bool mine = lane >= PAD && lane < 64 - PAD && x < W;   // columns this lane writes
     const int xc = min(max(x, 0), W - 1);
-    const float* pimg = pat0 + (long)b * sb + (long)xc * sw;
-    const float* zimg = z + img + xc;
+    // uniform 64-bit bases + 32-bit per-lane offsets (the host checked that they fit)
+    const float* pimg = pat0 + (long)b * sb;
+    const float* zimg = z + img;
+    float* rimg = raw + img;
+    uint8_t* limg = layer_u8 ? layer_u8 + img : nullptr;
+    const unsigned pcol = (unsigned)xc * (unsigned)sw;
 
     float pv[NR], zv[R];
 #pragma unroll
-    for (int r = 0; r < NR; ++r) pv[r] = pimg[(long)min(max(y0 - PAD + r, 0), H - 1) * sh];
+    for (int r = 0; r < NR; ++r) pv[r] = ld_at(pimg, (unsigned)min(max(y0 - PAD + r, 0), H - 1) * (unsigned)sh + pcol);
 #pragma unroll
-    for (int o = 0; o < R; ++o) zv[o] = zimg[min(y0 + o, H - 1) * W];
+    for (int o = 0; o < R; ++o) zv[o] = ld_at(zimg, (unsigned)(min(y0 + o, H - 1) * W + xc));
+    const LayerFast lfast = layer_fast_setup(lg);
+    stage_psf_stack<K>(smem, psf, lg.n_layers);   // after the loads above were issued: the latencies overlap
+    __syncthreads();
+    if (xs >= W) {
+        if (lane == 0) tilekey[kidx] = 0ull;      // below every real key
+        return;
+    }
 
     float w[KKP];
     int lcur = 0;
@@ -1065,7 +1131,10 @@ __global__ __launch_bounds__(NT) void code_pattern_fwd_roll_kernel(
             const int o = r - (K - 1);
             const int yo = y0 + o;
             const bool inb = mine && yo < H;
-            const int l = inb ? layer_of(zv[o], lg) : -1;
+            bool amb;
+            int l = layer_fast(zv[o], lg, lfast, amb);
+            if (__ballot(amb && inb) != 0ull) l = layer_of(zv[o], lg);   // rare: the exact chain for the whole row
+            l = inb ? l : -1;
             const int lw = l >= 0 ? l : lcur;
             if (__ballot(lw != lcur) != 0ull) {
                 lds_read4<KKP>(smem + lw * KKP, w);
@@ -1081,8 +1150,9 @@ __global__ __launch_bounds__(NT) void code_pattern_fwd_roll_kernel(
                 const uint32_t pos = 0xffffffffu - (uint32_t)(x * H + yo);   // first w, then first h
                 const unsigned long long k = ((unsigned long long)float_to_key(a) << 32) | pos;
                 key = k > key ? k : key;
-                raw[img + (long)yo * W + x] = a;
-                if (layer_u8) layer_u8[img + (long)yo * W + x] = (uint8_t)l;
+                const unsigned q = (unsigned)(yo * W + x);
+                st_at(rimg, q, a);
+                if (limg) st_at(limg, q, (uint8_t)l);
             }
         }
     }
@@ -1090,7 +1160,10 @@ __global__ __launch_bounds__(NT) void code_pattern_fwd_roll_kernel(
     if (lane == 0) tilekey[kidx] = key;
 }
 
-constexpr int kRollRows = 8;                      // output rows per strip of the rolling-row kernels
+#ifndef FC3D_ROLL_ROWS
+#define FC3D_ROLL_ROWS 8
+#endif
+constexpr int kRollRows = FC3D_ROLL_ROWS;         // output rows per strip of the rolling-row kernels
 
 // LDS plan of the wide kernels: returns bytes (0 = does not fit), and through the pointers whether
 // all L layers are staged (no per-tile layer range needed) and how many layers the weight area holds.
@@ -1171,7 +1244,9 @@ extern "C" int fc3d_code_pattern_fwd(void* stream, const float* pat0, int64_t pa
                      (!layer_u8 || aligned4(layer_u8));
     dim3 g(cdiv(W, TX), cdiv(H, TY), B), blk(NT);
     hipStream_t s = (hipStream_t)stream;
-    if (conv_flag && Kh == Kw) {
+    const bool fits32 = (long)H * W < (1L << 30) && pat_sh >= 0 && pat_sw >= 0 &&
+                        (long)(H - 1) * pat_sh + (long)(W - 1) * pat_sw < (1L << 30);   // byte offsets in 32 bits
+    if (conv_flag && Kh == Kw && fits32) {
 #define FC3D_FWD_ROLL_CASE(KV)                                                                                   \
     if (Kw == KV) {                                                                                              \
         const size_t rlds = (size_t)grid.n_layers * Roll<KV>::KKP * sizeof(float);                               \
@@ -1219,7 +1294,7 @@ extern "C" int fc3d_code_pattern_norm(void* stream, const float* raw, const uint
     if ((long)B * H * W >= (1L << 31) || B > 65535) return FC3D_ERANGE;
     const int ntiles = keys_per_image;
     const bool vec = (((long)H * W) % 4 == 0) && aligned16(raw) && aligned16(out);
-    dim3 g(cdiv((long)H * W, NT * 4), B), blk(NT);
+    dim3 g(cdiv((long)H * W, NT * 4 * NORM_V), B), blk(NT);
     auto k = vec ? code_pattern_norm_kernel<true> : code_pattern_norm_kernel<false>;
     FC3D_LAUNCH("code_pattern_norm", k, g, blk, 0, (hipStream_t)stream, raw, (const unsigned long long*)tilekey_u64,
                 ntiles, H, W, out, max_out, argmax_i32);
@@ -1243,7 +1318,7 @@ extern "C" int fc3d_code_pattern_bwd(void* stream, const float* g_out, const flo
     const long HW = (long)H * W;
     const int nred = cdiv(HW, RED_PX);
     float* partial = (float*)workspace;
-    if (conv_flag && Kh == Kw) {
+    if (conv_flag && Kh == Kw && HW < (1L << 30)) {
         constexpr int R = kRollRows;
 #define FC3D_BWD_ROLL_CASE(KV)                                                                                   \
     if (Kw == KV) {                                                                                              \

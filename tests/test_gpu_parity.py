@@ -63,6 +63,35 @@ def test_layer_index_bit_exact(mods, golden):
         assert np.array_equal(got.reshape(-1), g[f"layer_L{L}"].reshape(-1)), L
 
 
+def test_layer_index_every_float_of_a_binade(mods):
+    """The 5x5 kernel derives the layer with a reciprocal instruction and re-does ambiguous pixels
+    with the exact chain; every float in [0.5, 1) (the working range 0.69..0.95 lies inside) must
+    come out as the oracle's layer, for several layer grids."""
+    O, ops, synth, orc = mods["O"], mods["ops"], mods["synth"], mods["orc"]
+    H, W = 2048, 4096
+    bits = np.arange(H * W, dtype=np.uint32) + np.uint32(0x3F000000)      # 0.5 .. 1.0 - ulp
+    z = bits.view(np.float32).reshape(1, H, W, 1)
+    zt = dev(z)
+    pat = torch.ones_like(zt)
+    for L in (21, 41, 20):
+        psf = dev(synth.make_psfs(L, 5, "disc"))
+        _, layer, _, _ = ops.CodePatternFn.apply(pat, zt, psf, O._layer_grid(L), True)
+        got = layer.cpu().numpy().astype(np.int16).reshape(-1)
+        got[got == 255] = -1
+        ref = orc.layer_index(t(z), L).numpy().reshape(-1).astype(np.int16)
+        assert np.array_equal(got, ref), (L, int((got != ref).sum()))
+    # hostile depths take the same decisions as the exact chain
+    odd = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 1e-38, 3e38, -0.8, 0.8, 1e-3, 1e3],
+                   np.float32)
+    zz = np.full((1, 8, 64, 1), 0.8, np.float32)
+    zz[0, 3, :odd.size, 0] = odd
+    psf = dev(synth.make_psfs(21, 5, "disc"))
+    _, layer, _, _ = ops.CodePatternFn.apply(torch.ones(1, 8, 64, 1, device="cuda"), dev(zz), psf, O._layer_grid(21), True)
+    got = layer.cpu().numpy().astype(np.int16)
+    got[got == 255] = -1
+    assert np.array_equal(got[..., 0] if got.ndim == 4 else got, orc.layer_index(t(zz), 21)[..., 0].numpy())
+
+
 def _cases(g):
     for name in g["cases"]:
         tag, B, H, W, psf, K, conv, pk = str(name).split("|")
