@@ -31,7 +31,7 @@ SIGNATURES = {
                                       LayerGrid, P, P, P, POINTER(c_int)]),
     "fc3d_code_pattern_norm": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P]),
     "fc3d_code_pattern_bwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
-    "fc3d_pose_transforms": (c_int, [P, P, P, I64, c_int, P, P, P]),
+    "fc3d_pose_transforms": (c_int, [P, P, P, I64, c_int, P, P, P, P, c_size_t]),
     "fc3d_project_fwd": (c_int, [P, P, I64, I64, I64, I64, P, c_int, c_int, c_int, P]),
     "fc3d_project_bwd": (c_int, [P, P, P, I64, I64, I64, I64, P, c_int, c_int, c_int, P]),
     "fc3d_bilinear_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
@@ -40,7 +40,7 @@ SIGNATURES = {
     "fc3d_bilinear_bwd_img": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
     "fc3d_visible_mask": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P]),
     "fc3d_warp_p2c_fwd": (c_int, [P, P, P, I64, I64, I64, I64, P, I64, I64, I64, I64, P, P, c_int, c_int, c_int,
-                                  P, P, P, P]),
+                                  P, P, P, P, c_int]),
     "fc3d_points_fwd": (c_int, [P, P, P, P, P, I64, c_int, c_int, c_int, P]),
     "fc3d_points_bwd": (c_int, [P, P, P, P, P, I64, c_int, c_int, c_int, P]),
     "fc3d_zp_to_zc_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),

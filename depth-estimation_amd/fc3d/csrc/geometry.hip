@@ -63,10 +63,16 @@ __device__ inline void intrinsics_times(const float K[16], const float* A, float
         }
 }
 
+// The launch can also zero-fill a buffer (grid-stride, 16 bytes per lane and step): warp_p2c needs
+// its visibility mask cleared before the splat, and a separate fill would cost one more launch
+// than the few microseconds of work either of the two is.
 __global__ void pose_transforms_kernel(const float* __restrict__ pose, const float* __restrict__ Kin, long k_sb,
                                        int B, float* __restrict__ t_fwd, float* __restrict__ t_inv,
-                                       float* __restrict__ inv_out) {
+                                       float* __restrict__ inv_out, uint4* __restrict__ clear16, long n16,
+                                       uint8_t* __restrict__ clear_tail, int ntail) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    for (long i = b; i < n16; i += (long)gridDim.x * blockDim.x) clear16[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (b < ntail) clear_tail[b] = 0;
     if (b >= B) return;
     float K[16];
     for (int i = 0; i < 16; ++i) K[i] = Kin ? Kin[(long)b * k_sb + i] : 0.0f;
@@ -841,11 +847,20 @@ static inline bool use_fma(int H, int W) { return 16L * H * W >= 400; }
 using namespace fc3d;
 
 extern "C" int fc3d_pose_transforms(void* stream, const float* pose, const float* K, int64_t k_sb, int B,
-                                    float* t_fwd_out, float* t_inv_out, float* inv_out) {
+                                    float* t_fwd_out, float* t_inv_out, float* inv_out, void* clear,
+                                    size_t clear_bytes) {
     if (!pose || B <= 0) return FC3D_EINVAL;
     if (!K && (t_fwd_out || t_inv_out)) return FC3D_EINVAL;
-    FC3D_LAUNCH("pose_transforms", pose_transforms_kernel, dim3(cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, pose, K,
-                       (long)k_sb, B, t_fwd_out, t_inv_out, inv_out);
+    if (clear_bytes && !clear) return FC3D_EINVAL;
+    if (clear_bytes && !aligned16(clear)) return FC3D_EALIGN;
+    const long n16 = (long)(clear_bytes / 16);
+    const int ntail = (int)(clear_bytes % 16);
+    long blocks = cdiv(B, NT);
+    const long want = cdiv(n16, (long)NT * 4);          // about four 16-byte stores per lane
+    if (want > blocks) blocks = want < 4096 ? want : 4096;
+    FC3D_LAUNCH("pose_transforms", pose_transforms_kernel, dim3((unsigned)blocks), dim3(NT), 0, (hipStream_t)stream,
+                pose, K, (long)k_sb, B, t_fwd_out, t_inv_out, inv_out, (uint4*)clear, n16,
+                (uint8_t*)clear + n16 * 16, ntail);
     FC3D_LAUNCH_CHECK();
     return FC3D_OK;
 }
@@ -983,7 +998,8 @@ extern "C" int fc3d_visible_mask(void* stream, const float* grid, int B, int H, 
 extern "C" int fc3d_warp_p2c_fwd(void* stream, const float* Ip, const float* coord_p, int64_t p_sb, int64_t p_sc,
                                  int64_t p_sh, int64_t p_sw, const float* coord_c, int64_t c_sb, int64_t c_sc,
                                  int64_t c_sh, int64_t c_sw, const float* T_p2c, const float* T_c2p, int B, int H,
-                                 int W, float* Ic_masked, float* grid_p2c, float* grid_c2p, uint8_t* mask_u8) {
+                                 int W, float* Ic_masked, float* grid_p2c, float* grid_c2p, uint8_t* mask_u8,
+                                 int mask_is_clear) {
     if (!Ip || !coord_p || !coord_c || !T_p2c || !T_c2p || !Ic_masked || !grid_p2c || !grid_c2p || !mask_u8)
         return FC3D_EINVAL;
     if (int e = check_img(B, H, W)) return e;
@@ -993,7 +1009,7 @@ extern "C" int fc3d_warp_p2c_fwd(void* stream, const float* Ip, const float* coo
     hipStream_t s = (hipStream_t)stream;
     const bool fma = use_fma(H, W);
     dim3 g(cdiv((long)H * W, PX_PER_BLOCK), B), blk(NT);
-    FC3D_HIP(hipMemsetAsync(mask_u8, 0, (size_t)B * H * W, s));
+    if (!mask_is_clear) FC3D_HIP(hipMemsetAsync(mask_u8, 0, (size_t)B * H * W, s));
     {
         const int layout = pick_layout(coord_p, p_sc, p_sh, p_sw, W);
 #define ARGS coord_p, (long)p_sb, (long)p_sc, (long)p_sh, (long)p_sw, T_p2c, H, W, grid_p2c, mask_u8

@@ -119,8 +119,10 @@ class CodePatternFn(torch.autograd.Function):
 # --------------------------------------------------------------------------- #
 # geometry
 # --------------------------------------------------------------------------- #
-def pose_transforms(pose: torch.Tensor, K: torch.Tensor | None, want_fwd=False, want_inv=False, want_a=False):
-    """(K@pose, K@inv(pose), inv(pose)) as [B,4,4] tensors (None where not asked for)."""
+def pose_transforms(pose: torch.Tensor, K: torch.Tensor | None, want_fwd=False, want_inv=False, want_a=False,
+                    clear: torch.Tensor | None = None):
+    """(K@pose, K@inv(pose), inv(pose)) as [B,4,4] tensors (None where not asked for).
+    `clear`: a dense tensor the same launch fills with zeros (warp_p2c's visibility mask)."""
     dev = _need_gpu(pose, K)
     if pose.dim() != 3 or tuple(pose.shape[1:]) != (4, 4):
         raise RuntimeError(f"pose must be [B,4,4], got {tuple(pose.shape)}")
@@ -142,7 +144,10 @@ def pose_transforms(pose: torch.Tensor, K: torch.Tensor | None, want_fwd=False, 
     with torch.cuda.device(dev):
         _check(_lib.fc3d_pose_transforms(_stream(), p.data_ptr(), k_ptr, k_sb, B,
                                          tf.data_ptr() if want_fwd else None, ti.data_ptr() if want_inv else None,
-                                         a.data_ptr() if want_a else None), "fc3d_pose_transforms")
+                                         a.data_ptr() if want_a else None,
+                                         clear.data_ptr() if clear is not None else None,
+                                         clear.numel() * clear.element_size() if clear is not None else 0),
+               "fc3d_pose_transforms")
     return tf, ti, a
 
 
@@ -262,7 +267,8 @@ class WarpP2CFn(torch.autograd.Function):
     geometry_pytorch.py:255-281."""
 
     @staticmethod
-    def forward(ctx, Ip, coord_p, coord_c, T_p2c, T_c2p):
+    def forward(ctx, Ip, coord_p, coord_c, T_p2c, T_c2p, zero_mask):
+        # zero_mask: a [B,H,W] uint8 buffer of zeros to use as the visibility mask (see warp_mask_buffer)
         dev = _need_gpu(Ip, coord_p, coord_c, T_p2c, T_c2p)
         coord_p, sp = _coord_args(coord_p)
         coord_c, sc = _coord_args(coord_c)
@@ -274,12 +280,16 @@ class WarpP2CFn(torch.autograd.Function):
         Ic = torch.empty((B, H, W, 1), dtype=torch.float32, device=dev)
         gp2c = torch.empty((B, H, W, 2), dtype=torch.float32, device=dev)
         gc2p = torch.empty((B, H, W, 2), dtype=torch.float32, device=dev)
-        mask = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+        have_zero = zero_mask is not None
+        if have_zero and (tuple(zero_mask.shape) != (B, H, W) or zero_mask.dtype != torch.uint8 or
+                          not zero_mask.is_contiguous() or zero_mask.device != dev):
+            raise RuntimeError("warp_p2c: zero_mask must be a dense uint8 [B,H,W] tensor on the inputs' device")
+        mask = zero_mask if have_zero else torch.empty((B, H, W), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
             _check(_lib.fc3d_warp_p2c_fwd(_stream(), ip.data_ptr(), coord_p.data_ptr(), sp[0], sp[1], sp[2], sp[3],
                                           coord_c.data_ptr(), sc[0], sc[1], sc[2], sc[3], T_p2c.data_ptr(),
                                           T_c2p.data_ptr(), B, H, W, Ic.data_ptr(), gp2c.data_ptr(), gc2p.data_ptr(),
-                                          mask.data_ptr()), "fc3d_warp_p2c_fwd")
+                                          mask.data_ptr(), int(have_zero)), "fc3d_warp_p2c_fwd")
         ctx.save_for_backward(gc2p, mask)
         ctx.mark_non_differentiable(gp2c, gc2p, mask)
         ctx.set_materialize_grads(False)      # no zero tensors for the two grids and the mask
@@ -288,11 +298,11 @@ class WarpP2CFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_Ic, _g1, _g2, _g3):
         if g_Ic is None:
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         gc2p, mask = ctx.saved_tensors
         B, H, W, _ = gc2p.shape
         gi = _bilinear_bwd_img(_dense(g_Ic), gc2p, mask, B, H, W, 1, H, W)
-        return gi, None, None, None, None
+        return gi, None, None, None, None, None
 
 
 class PointsFn(torch.autograd.Function):

@@ -177,8 +177,11 @@ def warp_p2c(Ip, coord_p, coord_c, pose_p2c):
         grid_p2c = _ops.ProjectFn.apply(coord_p, T_p2c)
         return Ic * _ops.visible_mask(grid_p2c, 0), grid_p2c, grid_c2p
     K = _intrinsics_for(coord_p.shape[0], coord_p.device)
-    T_p2c, T_c2p, _ = _ops.pose_transforms(pose_p2c, K, want_fwd=True, want_inv=True)
-    Ic, grid_p2c, grid_c2p, _mask = _ops.WarpP2CFn.apply(Ip, coord_p, coord_c, T_p2c, T_c2p)
+    # the launch that forms the two transforms also clears the visibility mask for the splat
+    B, _, H, W = coord_p.shape
+    mask = torch.empty((B, H, W), dtype=torch.uint8, device=coord_p.device)
+    T_p2c, T_c2p, _ = _ops.pose_transforms(pose_p2c, K, want_fwd=True, want_inv=True, clear=mask)
+    Ic, grid_p2c, grid_c2p, _mask = _ops.WarpP2CFn.apply(Ip, coord_p, coord_c, T_p2c, T_c2p, mask)
     return Ic, grid_p2c, grid_c2p
 
 

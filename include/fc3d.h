@@ -104,9 +104,13 @@ int fc3d_code_pattern_bwd(void *stream, const float *g_out, const float *out, co
  * memory at K[b*k_sb + 4*i + j] (k_sb = 0 for one matrix shared by the batch).
  * Any output may be NULL (K may be NULL if only inv_out is wanted).  The inverse
  * is computed in fp64 and rounded once; the 4x4 products use separately rounded
- * multiplies and left-to-right adds like torch's small-matrix path.            */
+ * multiplies and left-to-right adds like torch's small-matrix path.
+ * clear / clear_bytes (NULL / 0 for none; 16-byte aligned): a buffer the same
+ * launch fills with zeros -- the visibility mask fc3d_warp_p2c_fwd would
+ * otherwise clear with a launch of its own.                                   */
 int fc3d_pose_transforms(void *stream, const float *pose, const float *K, int64_t k_sb, int B,
-                         float *t_fwd_out, float *t_inv_out, float *inv_out);
+                         float *t_fwd_out, float *t_inv_out, float *inv_out,
+                         void *clear, size_t clear_bytes);
 
 /* coord_transform, geometry_pytorch.py:68-90: grid[b][y][x] = (xu, yu)/(zu+1e-10),
  * u = T[b] * coord[b][:, y, x].  coord element (b,c,y,x) at
@@ -149,12 +153,14 @@ int fc3d_visible_mask(void *stream, const float *grid, int B, int H, int W, int 
 
 /* warp_p2c forward, geometry_pytorch.py:255-281, given T_p2c = K*pose and
  * T_c2p = K*inverse(pose): writes grid_p2c, grid_c2p, the visibility mask and
- * Ic_masked = sample(Ip, grid_c2p) * mask.                                    */
+ * Ic_masked = sample(Ip, grid_c2p) * mask.  mask_is_clear != 0: mask_u8 already
+ * holds zeros (see fc3d_pose_transforms), skip clearing it.                   */
 int fc3d_warp_p2c_fwd(void *stream, const float *Ip,
                       const float *coord_p, int64_t p_sb, int64_t p_sc, int64_t p_sh, int64_t p_sw,
                       const float *coord_c, int64_t c_sb, int64_t c_sc, int64_t c_sh, int64_t c_sw,
                       const float *T_p2c, const float *T_c2p, int B, int H, int W,
-                      float *Ic_masked, float *grid_p2c, float *grid_c2p, uint8_t *mask_u8);
+                      float *Ic_masked, float *grid_p2c, float *grid_c2p, uint8_t *mask_u8,
+                      int mask_is_clear);
 
 /* points_in_camera_coords, geometry_pytorch.py:44-65: out [B][H][W][4] =
  * (z*rx, z*ry, z*rz, 1).  Rays either separable (ray_x[W], ray_y[H], rz = 1:

@@ -310,7 +310,7 @@ def test_warp_small(mods, golden, monkeypatch):
     pose = t(g["pose"])
     K = orc.get_intrinsic(pose.shape[0], float(g["cx"]), float(g["cy"]))
     T_p2c, T_c2p = dev(g["T_p2c"]), dev(g["T_c2p"])
-    Ic2, gp2, gc2, mask = ops.WarpP2CFn.apply(dev(g["Ip"]), coord_p, coord_c, T_p2c, T_c2p)
+    Ic2, gp2, gc2, mask = ops.WarpP2CFn.apply(dev(g["Ip"]), coord_p, coord_c, T_p2c, T_c2p, None)
     assert np.array_equal(gp2.cpu().numpy(), g["grid_p2c"])
     assert np.array_equal(gc2.cpu().numpy(), g["grid_c2p"])
     assert np.array_equal(mask.cpu().numpy()[..., None], g["mask"])
@@ -359,7 +359,7 @@ def test_warp_native_800x1200(mods, golden):
     # this end-to-end check, bit-exact bar below once the reference's own matrices are used.
     assert rel_err(Ic[:, ::s, ::s].cpu().numpy(), g["Ic_sub"]) < 1e-3
     assert abs(float(Ic.double().sum()) - float(g["Ic_sum"])) < 1e-5 * float(g["Ic_sum"])
-    Ic2, gp2, gc2, mk = mods["ops"].WarpP2CFn.apply(dev(Ip), coord_p, coord_c, dev(g["T_p2c"]), dev(g["T_c2p"]))
+    Ic2, gp2, gc2, mk = mods["ops"].WarpP2CFn.apply(dev(Ip), coord_p, coord_c, dev(g["T_p2c"]), dev(g["T_c2p"]), None)
     assert np.array_equal(gc2[:, ::s, ::s].cpu().numpy(), g["grid_c2p_sub"])
     assert np.array_equal(Ic2[:, ::s, ::s].cpu().numpy(), g["Ic_sub"])
     assert np.array_equal(np.packbits(mk.cpu().numpy().reshape(-1)), g["mask_bits"])

@@ -25,7 +25,7 @@ def test_cabi_exports_every_declared_symbol():
     assert lib.fc3d_status_string(-1).decode().startswith("invalid")
     # argument validation happens before any device work
     assert lib.fc3d_visible_mask(None, None, 1, 4, 4, 0, None, None) == -1
-    assert lib.fc3d_code_pattern_fwd_workspace(32, 512, 512) == 32 * 256 * 8
+    assert lib.fc3d_code_pattern_fwd_workspace(32, 512, 512) == 32 * 768 * 8   # 12 strips x 64 row blocks
     assert lib.fc3d_bilinear_bwd_img_workspace(2, 64, 96, 1, 64, 96) == 2 * 24 * (16 + 1024 * 4)
 
 
