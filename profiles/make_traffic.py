@@ -25,6 +25,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # rocprofv3 kernel symbol -> the name bench.py's event profiler uses
 NAMES = (
+    ("code_pattern_fwd_roll_kernel", "code_pattern_fwd"), ("code_pattern_bwd_roll_kernel", "code_pattern_bwd"),
+    ("code_pattern_bwd_max_kernel", "code_pattern_bwd_max"),
     ("code_pattern_fwd_wide_kernel", "code_pattern_fwd"), ("code_pattern_fwd_kernel", "code_pattern_fwd"),
     ("code_pattern_norm_kernel", "code_pattern_norm"), ("code_pattern_bwd_reduce_kernel", "code_pattern_bwd_reduce"),
     ("code_pattern_bwd_wide_kernel", "code_pattern_bwd"), ("code_pattern_bwd_kernel", "code_pattern_bwd"),
