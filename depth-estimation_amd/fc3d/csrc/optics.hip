@@ -905,8 +905,9 @@ __global__ __launch_bounds__(NT) void code_pattern_bwd_wide_kernel(
 // Backward (scatter form): source pixel p = (y, x) of layer l adds PSF[l][dy][dx] * graw[p] to
 // output (y + dy - pad, x + dx - pad).  Each lane keeps the K*K weights of its own pixel's layer
 // in registers (reloaded from LDS only on rows where some lane's layer differs from the row
-// above), forms its K products for one PSF row and passes them sideways Horner fashion: one
-// shift per column step, K-1 shifts per PSF row.  Output rows live in rolling accumulators.
+// above) and adds its K*K products into rolling accumulators, one per output row and column
+// offset; when an output row is complete the K column sums are handed sideways Horner fashion,
+// one shift per column step.
 // ---------------------------------------------------------------------------------------
 template <int K>
 struct Roll {
@@ -1004,9 +1005,13 @@ __global__ __launch_bounds__(NT) void code_pattern_bwd_roll_kernel(
     float w[KKP];
     int lcur = 0;
     lds_read4<KKP>(smem, w);
-    float acc[R];
+    // acc[o][dx]: what this lane's pixels send to output row o, column x + dx - pad.  The sideways
+    // hand-over waits until the row is complete: K-1 shifts per output row, not per source row.
+    float acc[R][K];
 #pragma unroll
-    for (int o = 0; o < R; ++o) acc[o] = 0.0f;
+    for (int o = 0; o < R; ++o)
+#pragma unroll
+        for (int dx = 0; dx < K; ++dx) acc[o][dx] = 0.0f;
 
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
@@ -1022,21 +1027,22 @@ __global__ __launch_bounds__(NT) void code_pattern_bwd_roll_kernel(
         for (int dy = 0; dy < K; ++dy) {
             const int o = r + dy - 2 * PAD;       // output row (from y0) fed by source row r through PSF row dy
             if (o < 0 || o >= R) continue;
-            const float* wr = w + dy * K;
-            float up = wr[K - 1] * v;             // travels to higher lanes
 #pragma unroll
-            for (int dx = K - 2; dx > PAD; --dx) up = fmaf(wr[dx], v, from_lane_below(up));
-            up = from_lane_below(up);
-            float dn = wr[0] * v;                 // travels to lower lanes
-#pragma unroll
-            for (int dx = 1; dx < PAD; ++dx) dn = fmaf(wr[dx], v, from_lane_above(dn));
-            dn = from_lane_above(dn);
-            acc[o] = (fmaf(wr[PAD], v, acc[o]) + up) + dn;
+            for (int dx = 0; dx < K; ++dx) acc[o][dx] = fmaf(w[dy * K + dx], v, acc[o][dx]);
         }
         if (r >= 2 * PAD) {
             const int o = r - 2 * PAD;            // complete: its last source row was this one
             const int yo = y0 + o;
-            if (mine && yo < H) st_at(gp, (unsigned)(yo * W + x), acc[o]);
+            float up = acc[o][K - 1];             // travels to higher lanes, one column per step
+#pragma unroll
+            for (int dx = K - 2; dx > PAD; --dx) up = acc[o][dx] + from_lane_below(up);
+            up = from_lane_below(up);
+            float dn = acc[o][0];                 // travels to lower lanes
+#pragma unroll
+            for (int dx = 1; dx < PAD; ++dx) dn = acc[o][dx] + from_lane_above(dn);
+            dn = from_lane_above(dn);
+            const float res = (acc[o][PAD] + up) + dn;
+            if (mine && yo < H) st_at(gp, (unsigned)(yo * W + x), res);
         }
     }
 }
@@ -1163,7 +1169,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 #ifndef FC3D_ROLL_ROWS
 #define FC3D_ROLL_ROWS 8
 #endif
-constexpr int kRollRows = FC3D_ROLL_ROWS;         // output rows per strip of the rolling-row kernels
+#ifndef FC3D_ROLL_ROWS_BWD
+#define FC3D_ROLL_ROWS_BWD 16
+#endif
+constexpr int kRollRows = FC3D_ROLL_ROWS;         // output rows per strip of the rolling-row kernels: forward,
+constexpr int kRollRowsBwd = FC3D_ROLL_ROWS_BWD;  // backward
 
 // LDS plan of the wide kernels: returns bytes (0 = does not fit), and through the pointers whether
 // all L layers are staged (no per-tile layer range needed) and how many layers the weight area holds.
@@ -1220,7 +1230,7 @@ extern "C" size_t fc3d_code_pattern_fwd_workspace(int B, int H, int W) {
 extern "C" size_t fc3d_code_pattern_bwd_workspace(int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0) return 0;
     const long a = cdiv((long)H * W, RED_PX);
-    const long r = (long)cdiv(cdiv(W, Roll<7>::SW), NT / 64) * (NT / 64) * cdiv(H, kRollRows);
+    const long r = (long)cdiv(cdiv(W, Roll<7>::SW), NT / 64) * (NT / 64) * cdiv(H, kRollRowsBwd);
     return (size_t)B * (a > r ? a : r) * sizeof(float);
 }
 
@@ -1319,7 +1329,7 @@ extern "C" int fc3d_code_pattern_bwd(void* stream, const float* g_out, const flo
     const int nred = cdiv(HW, RED_PX);
     float* partial = (float*)workspace;
     if (conv_flag && Kh == Kw && HW < (1L << 30)) {
-        constexpr int R = kRollRows;
+        constexpr int R = kRollRowsBwd;
 #define FC3D_BWD_ROLL_CASE(KV)                                                                                   \
     if (Kw == KV) {                                                                                              \
         const size_t rlds = (size_t)L * Roll<KV>::KKP * sizeof(float);                                           \
