@@ -53,6 +53,17 @@ __device__ __forceinline__ float key_to_float(uint32_t k) {
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
 
+// Uniform 64-bit base + 32-bit per-lane *byte* offset: the form the global load/store
+// instructions take directly (scalar base register pair + one offset VGPR), no 64-bit lane math.
+template <typename T>
+__device__ __forceinline__ T ld_at(const T* base, unsigned elem) {
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + elem * (unsigned)sizeof(T));
+}
+template <typename T>
+__device__ __forceinline__ void st_at(T* base, unsigned elem, T v) {
+    *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + elem * (unsigned)sizeof(T)) = v;
+}
+
 template <typename T>
 __device__ __forceinline__ T wave_max(T v) {
 #pragma unroll

@@ -419,24 +419,29 @@ __device__ __forceinline__ int wave_max_dpp(int v) {
 __device__ __forceinline__ void load_tile_taps(const float* __restrict__ g_out, const float* __restrict__ grid,
                                                const uint8_t* __restrict__ mask_u8, long tb, int Ht, int Wt, int Hs,
                                                int Ws, int tx0, int ty0, int lane, PxTaps px[4]) {
+    // all twelve loads up front, unconditionally, from clamped (always valid) positions: one
+    // memory latency per tile; a load inside an `if` would cost one each
     const int x = tx0 + (lane & 31);
+    const float2* gb = reinterpret_cast<const float2*>(grid) + tb;
+    const float* vb = g_out + tb;
+    const uint8_t* mb = mask_u8 ? mask_u8 + tb : nullptr;
     float2 g[4];
+    float gv[4];
+    uint8_t mk[4];
     bool vis[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int y = ty0 + (lane >> 5) + 2 * k;
         vis[k] = (x < Wt) && (y < Ht);
-        px[k].v = 0.0f;
-        g[k] = make_float2(0.f, 0.f);
-        if (vis[k]) {
-            const long q = tb + (long)y * Wt + x;
-            if (mask_u8) vis[k] = mask_u8[q] != 0;
-            g[k] = *reinterpret_cast<const float2*>(grid + q * 2);
-            px[k].v = g_out[q];
-        }
+        const unsigned q = (unsigned)(min(y, Ht - 1) * Wt + min(x, Wt - 1));
+        g[k] = ld_at(gb, q);
+        gv[k] = ld_at(vb, q);
+        mk[k] = mb ? ld_at(mb, q) : (uint8_t)1;
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
+        vis[k] = vis[k] && mk[k] != 0;
+        px[k].v = vis[k] ? gv[k] : 0.0f;
         px[k].t = make_taps(g[k].x, g[k].y, Hs, Ws);
         px[k].on = vis[k] && (px[k].t.x0 != px[k].t.x1) && (px[k].t.y0 != px[k].t.y1);
     }
@@ -492,7 +497,7 @@ __global__ __launch_bounds__(NT) void bilinear_bwd_img_scatter_kernel(
     const float* __restrict__ g_out, const float* __restrict__ grid, const uint8_t* __restrict__ mask_u8, int Hs,
     int Ws, int Ht, int Wt, int tiles_x, int ntiles, TileMeta* __restrict__ meta, float* __restrict__ slab,
     float* __restrict__ g_img) {
-    __shared__ float s_win[NT / 64][WIN_CAP];
+    __shared__ __align__(16) float s_win[NT / 64][WIN_CAP];
     __shared__ uint8_t s_own[NT / 64][WIN_CAP];
     const int b = blockIdx.y;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -516,7 +521,10 @@ __global__ __launch_bounds__(NT) void bilinear_bwd_img_scatter_kernel(
     const int n = fits ? ww * wh : 0;
     volatile float* w = s_win[wv];
     volatile uint8_t* own = s_own[wv];
-    for (int i = lane; i < n; i += 64) w[i] = 0.0f;
+    {   // clear the window, 16 bytes per lane and step (a few cells past n do no harm: n <= WIN_CAP)
+        float4* w4 = reinterpret_cast<float4*>(s_win[wv]);
+        for (int i = lane; 4 * i < n; i += 64) w4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     if (n > 0) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -530,13 +538,14 @@ __global__ __launch_bounds__(NT) void bilinear_bwd_img_scatter_kernel(
     if (DIRECT) {
         float* o = g_img + (long)b * Hs * Ws;
         if (n > 0) {
-            o += (long)ymin * Ws + xmin;
+            const unsigned o0 = (unsigned)(ymin * Ws + xmin);
             const unsigned magic = ((1u << 20) + (unsigned)ww - 1u) / (unsigned)ww;   // i / ww == (i * magic) >> 20 while i * ww < 2^20
             for (int i = lane; i < n; i += 64) {
                 const float v = w[i];
-                const int r = (int)(((unsigned)i * magic) >> 20);
-                const int c = i - r * ww;
-                if (v != 0.0f) atomicAdd(o + (long)r * Ws + c, v);
+                const unsigned r = ((unsigned)i * magic) >> 20;
+                const unsigned c = (unsigned)i - r * (unsigned)ww;
+                if (v != 0.0f)
+                    atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(o) + (o0 + r * (unsigned)Ws + c) * 4u), v);
             }
         } else if (!empty) {
 #pragma unroll
@@ -905,6 +914,7 @@ extern "C" int fc3d_bilinear_fwd(void* stream, const float* img, const float* gr
     if (int e = check_img(B, Hs, Ws)) return e;
     if (int e = check_img(B, Ht, Wt)) return e;
     if ((long)B * Hs * Ws * C >= (1L << 31) || (long)B * Ht * Wt * C >= (1L << 31)) return FC3D_ERANGE;
+    if ((long)Ht * Wt >= (1L << 29) || (long)Hs * Ws >= (1L << 30)) return FC3D_ERANGE;   // per-image byte offsets are 32-bit
     if (!aligned4(img) || (reinterpret_cast<uintptr_t>(grid) & 7u)) return FC3D_EALIGN;
     const long np = (long)Ht * Wt;
     FC3D_LAUNCH("bilinear_fwd", bilinear_fwd_kernel, dim3(cdiv(np, NT), B), dim3(NT), 0, (hipStream_t)stream, img, grid, mask_u8,

@@ -917,17 +917,6 @@ struct Roll {
     static constexpr int KKP = (KK + 3) & ~3;    // one layer's PSF, padded to whole float4s
 };
 
-// Uniform 64-bit base + 32-bit per-lane *byte* offset: the form the global load/store
-// instructions take directly (scalar base register pair + one offset VGPR), no 64-bit lane math.
-template <typename T>
-__device__ __forceinline__ T ld_at(const T* base, unsigned elem) {
-    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + elem * (unsigned)sizeof(T));
-}
-template <typename T>
-__device__ __forceinline__ void st_at(T* base, unsigned elem, T v) {
-    *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + elem * (unsigned)sizeof(T)) = v;
-}
-
 // lane i receives lane i-1's value (lane 0: zero) / lane i+1's value (lane 63: zero)
 __device__ __forceinline__ float from_lane_below(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));   // wave_shr:1
