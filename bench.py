@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch override")
     ap.add_argument("--psf-k", type=int, default=None)
     ap.add_argument("--psf-kind", default="disc")
+    ap.add_argument("--launch", choices=("graph", "eager"), default="graph",
+                    help="graph: the step is captured once into a HIP graph and replayed (same kernels, same "
+                         "order, same buffers; no per-launch host cost); eager: every launch issued from Python")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
@@ -129,20 +132,46 @@ def cpu_baseline(wl, seconds):
         _, Ic, _, _ = orc.image_formation(pat, z_p, cp, cc, pose, wl["psfs"], W / 2, H / 2)
         Ic.backward(g)
 
-    one()
-    n, t0 = 0, time.perf_counter()
-    best = float("inf")
-    while True:
-        a = time.perf_counter()
+    def best_of(limit_s, limit_n):
         one()
-        b = time.perf_counter()
-        best = min(best, b - a)
-        n += 1
-        if b - t0 > seconds or n >= 50:
-            break
-    return dict(value=Bs / best, unit="captures/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{n} repeats of batch {Bs} at {H}x{W}, L={L}, K={cfg['K']} (best of {n}); "
-                       f"host cpu_count={os.cpu_count()}")
+        n, t0, best = 0, time.perf_counter(), float("inf")
+        while True:
+            a = time.perf_counter()
+            one()
+            b = time.perf_counter()
+            best = min(best, b - a)
+            n += 1
+            if b - t0 > limit_s or n >= limit_n:
+                return best, n
+
+    threads = torch.get_num_threads()
+    best, n = best_of(seconds, 50)
+    torch.set_num_threads(1)
+    try:
+        best1, n1 = best_of(seconds / 2, 10)
+    finally:
+        torch.set_num_threads(threads)
+    return dict(value=Bs / best, unit="captures/s", cores=threads, kind="port",
+                value_1core=Bs / best1,
+                sample=f"{n} repeats of batch {Bs} at {H}x{W}, L={L}, K={cfg['K']} (best of {n}) on {threads} threads, "
+                       f"{n1} repeats on 1 thread; host cpu_count={os.cpu_count()}")
+
+
+def copy_bandwidth(device, mib=512, iters=10):
+    """Device-to-device copy rate (read + write bytes per second): what a plain streaming kernel
+    reaches on this box, as a yardstick next to the nominal peak."""
+    n = mib * 1024 * 1024 // 4
+    src = torch.empty(n, dtype=torch.float32, device=device).fill_(1.0)
+    dst = torch.empty_like(src)
+    for _ in range(2):
+        dst.copy_(src)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        dst.copy_(src)
+    b.record()
+    torch.cuda.synchronize()
+    return 2.0 * n * 4 * iters / (a.elapsed_time(b) * 1e-3)
 
 
 def main():
@@ -167,7 +196,13 @@ def main():
     wl, tens = build_inputs(args, rank, device)
     cfg = wl["cfg"]
     B, H, W = cfg["B"], cfg["H"], cfg["W"]
-    step = make_step(tens)
+    step = make_step(tens)          # eager step: used for the per-kernel event pass in either mode
+    timed_step, launch = step, "eager"
+    if args.launch == "graph":
+        from fc3d.graphs import GraphedImageFormation
+        gf = GraphedImageFormation(tens["pat"], tens["z_p"], tens["coord_p"], tens["coord_c"], tens["pose"],
+                                   tens["g"], tens["L"])
+        timed_step, launch = gf.replay, "hip_graph"
 
     def barrier():
         if dist is not None:
@@ -175,11 +210,11 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step()
+        timed_step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        timed_step()
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -221,10 +256,12 @@ def main():
             "config": {"workload": f"{args.workload}: {B}x{H}x{W} per GPU, L={cfg['L']} depth layers, "
                                    f"{cfg['K']}x{cfg['K']} '{args.psf_kind}' PSFs, pose theta<={cfg['theta_deg']}deg; "
                                    "codePattern -> warp_p2c fwd + bwd to pattern[...,0]",
-                       "global_batch": world * B, "parallelism": f"batch-sharded x{world}, no collective"},
+                       "global_batch": world * B, "parallelism": f"batch-sharded x{world}, no collective",
+                       "launch": launch},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
                          "kernel_avg_us": dk["avg_us"], "alg_bytes_per_launch": dk["alg_bytes_per_launch"],
+                         "measured_copy_GBps": copy_bandwidth(device) / 1e9,
                          "path_alg_bytes_per_capture": 100 * H * W,
                          "path_frac_per_gpu": (value / world) * 100 * H * W / HBM_PEAK,
                          "gpu_kernel_us_per_step": gpu_sum_us},

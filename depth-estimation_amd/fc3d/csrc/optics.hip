@@ -915,6 +915,7 @@ struct Roll {
     static constexpr int SW = 64 - (K - 1);      // output columns per strip
     static constexpr int KK = K * K;
     static constexpr int KKP = (KK + 3) & ~3;    // one layer's PSF, padded to whole float4s
+    static constexpr int FWD_WAVES = K <= 5 ? 6 : 3;   // wavefronts per SIMD the forward kernel is compiled for
 };
 
 // lane i receives lane i-1's value (lane 0: zero) / lane i+1's value (lane 63: zero)
@@ -1067,10 +1068,12 @@ __global__ __launch_bounds__(NT) void code_pattern_bwd_max_kernel(
 // K-1 shifts and kept for K rows; a finished output row takes K*K fused multiply-adds with the
 // weights of its own pixel's layer (dy, then dx ascending, like the other forward kernels).
 // One max key per wavefront strip goes to the normalisation pass.
-// (six wavefronts per SIMD: the kernel waits on memory more than it computes, and two more
-// resident wavefronts are worth the couple of spilled registers the limit costs)
+// (K <= 5: six wavefronts per SIMD -- the kernel waits on memory more than it computes, and one
+// more resident wavefront is worth the couple of spilled registers the limit costs; the 7x7
+// window and weights need about 100 more registers and are left to the compiler's own choice)
 template <int K, int R>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6))) void code_pattern_fwd_roll_kernel(
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(Roll<K>::FWD_WAVES, Roll<K>::FWD_WAVES)))
+void code_pattern_fwd_roll_kernel(
     const float* __restrict__ pat0, long sb, long sh, long sw, const float* __restrict__ z,
     const float* __restrict__ psf, int H, int W, fc3d_layer_grid lg, float* __restrict__ raw,
     uint8_t* __restrict__ layer_u8, unsigned long long* __restrict__ tilekey) {

@@ -1,0 +1,66 @@
+"""HIP-graph replay of the image-formation step.
+
+One capture (codePattern -> warp_p2c forward, backward to pattern[...,0]) is eight short kernel
+launches plus two fills; issued one by one from Python (ctypes + autograd) they cost about 250 us
+of host time per step, which is more than the kernels themselves take at 32x512x512.  Capturing
+the step once into a HIP graph (torch.cuda.CUDAGraph: hipStreamBeginCapture / hipGraphLaunch on
+ROCm) and replaying it removes that cost: the launches are the same, in the same order, on the
+same buffers; only the host-side issue changes.
+
+The library needs nothing special for this: every entry point is asynchronous on the stream it is
+given, allocates nothing and returns no device-dependent value to the host.
+"""
+from __future__ import annotations
+
+import torch
+
+import geometry_pytorch as G
+import optics_pytorch as O
+
+
+class GraphedImageFormation:
+    """Static-buffer replay of  Ip = codePattern(pattern, z_p);  Ic, grid_p2c, grid_c2p =
+    warp_p2c(Ip, coord_p, coord_c, pose);  Ic.backward(upstream_grad).
+
+    The tensors passed in are the graph's input buffers: write new data into them in place
+    (``t.copy_(new)``) between replays.  ``pattern`` must be a leaf that requires grad; its
+    ``.grad`` is the static output gradient, rewritten by every replay.  ``outputs`` holds the
+    forward results (also static)."""
+
+    def __init__(self, pattern, z_p, coord_p, coord_c, pose, upstream_grad, n_layers, is_conv_psf=True,
+                 warmup: int = 3):
+        if not (pattern.is_leaf and pattern.requires_grad):
+            raise ValueError("pattern must be a leaf tensor that requires grad")
+        self.pattern, self.z_p, self.coord_p, self.coord_c, self.pose = pattern, z_p, coord_p, coord_c, pose
+        self.upstream_grad, self.n_layers, self.conv = upstream_grad, n_layers, is_conv_psf
+        self.outputs = None
+        self.graph = None
+        self._capture(warmup)
+
+    def _step(self):
+        Ip = O.codePattern(self.pattern, self.z_p, is_conv_psf=self.conv, n_layers=self.n_layers)
+        Ic, gp2c, gc2p = G.warp_p2c(Ip, self.coord_p, self.coord_c, self.pose)
+        Ic.backward(self.upstream_grad)
+        return Ip, Ic, gp2c, gc2p
+
+    def _capture(self, warmup):
+        dev = self.pattern.device
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):              # warm-up off the default stream, as capture requires
+            for _ in range(max(1, warmup)):
+                self.pattern.grad = None
+                self._step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.pattern.grad = None                   # so that .grad is allocated from the graph's pool
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            outs = self._step()
+        self.graph = g
+        self.outputs = tuple(o.detach() for o in outs)
+
+    def replay(self):
+        """Runs the captured step on the current stream; returns (Ic, pattern.grad) static tensors."""
+        self.graph.replay()
+        return self.outputs[1], self.pattern.grad
