@@ -360,20 +360,21 @@ __global__ __launch_bounds__(NT) void bilinear_bwd_grid_kernel(const float* __re
 }
 
 // ---------------------------------------------------------------------------------------
-// d out / d img for C == 1: scatter-add without atomics
+// d out / d img for C == 1: scatter-add through per-wavefront LDS windows
 //
-// Pass 1 (scatter): each wavefront owns a 32x8 tile of target pixels.  It finds the bounding
-//   box of the source pixels its taps touch (DPP min/max), accumulates all taps into a private
-//   LDS window of that box and stores the window compactly ("slab") plus the box.  LDS float
-//   atomics retire about one lane every three cycles on this chip, so the window is updated
-//   with plain read-add-write; lanes of one instruction that hit the same cell are serialised
-//   by an election through a byte-sized owner array (the last writer of a ds_write wins, the
-//   winners add, the rest retry), and LDS executes a wavefront's instructions in order, so
-//   successive taps see each other's updates.
-// Pass 2 (merge): each workgroup owns a 64x16 tile of the source image and adds, in ascending
-//   tile order, every slab whose box overlaps it -> fixed summation order, reproducible bits.
-// Pass 3 (overflow): tiles whose box did not fit a window (discontinuous warps) are added with
-//   global float atomics.
+// Scatter: each wavefront owns a 32x8 tile of target pixels.  It finds the bounding box of the
+//   source pixels its taps touch (DPP min/max) and sums all taps into a private LDS window of
+//   that box.  LDS float atomics retire about one lane every three cycles on this chip, so the
+//   window is updated with plain read-add-write; lanes of one instruction that hit the same cell
+//   are serialised by an election through a byte-sized owner array.
+// Then either (no workspace; the default of the Python wrappers)
+//   the window is added to the zero-filled gradient image with global float atomics: about one
+//   atomic per pixel instead of four, but last-bit differences from run to run,
+// or (workspace given; torch's deterministic mode)
+//   the window is stored compactly ("slab") with its box, and a merge pass lets each workgroup
+//   own a 64x16 tile of the source image and add, in ascending tile order, every slab whose box
+//   overlaps it -> fixed summation order, reproducible bits; tiles whose box did not fit a window
+//   (discontinuous warps) are added with global float atomics in an overflow pass.
 //
 // A sample whose two x corners (or two y corners) were clamped onto the same source pixel
 // contributes +w and -w to that pixel, i.e. exactly nothing; such samples are skipped.
@@ -447,34 +448,15 @@ __device__ __forceinline__ void load_tile_taps(const float* __restrict__ g_out, 
     }
 }
 
-// win[cell] += val for every active lane; lanes aiming at the same cell take turns.  The common
-// case (no two lanes of this instruction share a cell) is straight-line code: elect, add, one
-// vote; only a collision enters the retry loop.
-__device__ __forceinline__ void window_add(volatile float* win, volatile uint8_t* own, int cell, float val,
-                                           bool active, int lane) {
-    bool pend = active;
-    if (pend) {
-        own[cell] = (uint8_t)lane;
-        if (own[cell] == (uint8_t)lane) {          // LDS runs a wavefront's ds ops in order: this reads the winner
-            win[cell] = win[cell] + val;
-            pend = false;
-        }
-    }
-    while (__builtin_expect(__ballot(pend) != 0, 0)) {
-        if (pend) {
-            own[cell] = (uint8_t)lane;
-            if (own[cell] == (uint8_t)lane) {
-                win[cell] = win[cell] + val;
-                pend = false;
-            }
-        }
-    }
-}
-
-// The four taps of one sample: a sample that is kept has x1 = x0 + 1 and y1 = y0 + 1, so its cells
-// are c, c+1, c+ww, c+ww+1, and lanes with distinct base cells c have distinct cells in each of
-// the four add instructions.  One election on c therefore covers all four; the adds themselves
-// stay separate instructions in program order because lane i's c+1 may be lane j's c.
+// Adds the four taps of one sample per lane into the window; lanes that aim at the same cells
+// take turns.  A lane announces itself by writing its id into a byte array at its base cell and
+// reads it back: LDS executes a wavefront's instructions in order and the last writer of one
+// store instruction wins, so exactly one lane per contested cell sees its own id, adds, and the
+// others retry (straight-line code in the common case of no collision).  A sample that is kept
+// has x1 = x0 + 1 and y1 = y0 + 1, so its cells are c, c+1, c+ww, c+ww+1, and lanes with distinct
+// base cells c have distinct cells in each of the four add instructions: one election on c
+// covers all four.  The adds stay separate instructions in program order because lane i's c+1
+// may be lane j's c.
 __device__ __forceinline__ void window_add4(volatile float* win, volatile uint8_t* own, int c, int ww, float v00,
                                             float v10, float v01, float v11, bool active, int lane) {
     bool pend = active;

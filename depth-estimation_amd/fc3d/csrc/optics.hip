@@ -1,15 +1,19 @@
 // Depth-layered PSF blur (codePattern, optics_pytorch.py:71-121) for gfx950.
 //
-// Forward: one workgroup owns a 64x16 output tile.  It derives each pixel's depth layer
-// from z on the fly (no [B,H,W,L] one-hot mask ever exists), stages channel 0 of the
-// pattern with its K-1 halo and the PSFs of only the layers present in the tile into LDS,
-// and lets every lane accumulate 4 neighbouring outputs with a sliding register window.
-// The per-image maximum is found without atomics: each tile writes one packed 64-bit key
-// (ordered value | position priority) and the normalisation pass reduces an image's keys.
+// Every pixel's depth layer is derived from z on the fly (no [B,H,W,L] one-hot mask ever
+// exists).  The per-image maximum is found without atomics: each tile / strip writes one packed
+// 64-bit key (ordered value | position priority) and the normalisation pass reduces an image's
+// keys.  The gradient flows to channel 0 of the pattern only.
 //
-// Backward (w.r.t. pattern[...,0]): a deterministic two-level sum gives sum(g*out) per
-// image, then the transposed convolution is evaluated in gather form: every output pixel
-// walks its K x K neighbours p and uses the PSF of *p's* layer.
+// Three kernel families, picked by PSF size:
+//   rolling-row (3x3, 5x5, 7x7; near the end of this file): one pixel column per lane, column
+//       neighbours through wavefront shifts, PSF weights of the lane's layer in registers;
+//   wide LDS tiles (other odd widths up to 33, images at least 192 wide): 256x8 tiles, pattern
+//       and halo staged in LDS, 4x2 outputs per lane;
+//   generic 64x16 LDS tiles (everything else, and is_conv_psf=False).
+// In the LDS families the backward pass first sums g*out per image (deterministic two-level
+// sum), then evaluates the transposed convolution in gather form: every output pixel walks its
+// K x K neighbours p and uses the PSF of *p's* layer.
 #include "fc3d_common.h"
 
 namespace fc3d {
