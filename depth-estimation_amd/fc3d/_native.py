@@ -43,6 +43,8 @@ SIGNATURES = {
                                   P, P, P, P, c_int]),
     "fc3d_points_fwd": (c_int, [P, P, P, P, P, I64, c_int, c_int, c_int, P]),
     "fc3d_points_bwd": (c_int, [P, P, P, P, P, I64, c_int, c_int, c_int, P]),
+    "fc3d_reproject_fwd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
+    "fc3d_reproject_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "fc3d_zp_to_zc_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
     "fc3d_zp_to_zc_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
     "fc3d_profile_enable": (c_int, [c_int]),

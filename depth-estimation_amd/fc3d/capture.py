@@ -115,18 +115,30 @@ def forward_model(z_p, z_c, pose_p2c, n_layers=21, is_conv_psf=True, crop=None, 
     return (c(Ic_scaled), c(Ic_mask), c(xyz_cView), c(xy), c(z_c), c(z_p), pose_p2c, z_p, c(Ic), Ip_coded, Ic_scaled)
 
 
-def reProj_IpGT(zp_cView, pose_p2c, xy, Ic, zcGT, maskC, IpGT):
-    """Re-projection loss; train_pytorch.py:179-211 (one crop per sample)."""
-    me = erode(maskC, 5)
-    zp = zp_cView * me
+def reproject(zp, pose_p2c, xy, IpGT, fused=True):
+    """(zc, Ic_reProj) of the re-projection chain, train_pytorch.py:194-202: camera-view projector
+    depth -> camera depth -> scene points -> projector pixel -> sampled pattern.  fused=True runs
+    the chain as one kernel per direction (gradient w.r.t. zp only); fused=False composes the
+    drop-in operators as the reference does (also differentiable w.r.t. xy and IpGT)."""
+    from . import ops
+    if fused and not (torch.is_grad_enabled() and (xy.requires_grad or IpGT.requires_grad or pose_p2c.requires_grad)):
+        K = G._intrinsics_for(zp.shape[0], zp.device)
+        _, T_c2p, pose_c2p = ops.pose_transforms(pose_p2c.detach(), K, want_inv=True, want_a=True)
+        return ops.ReprojectFn.apply(zp, xy, pose_c2p, T_c2p, IpGT)
     zc = G.zp_cView_to_zc(zp, pose_p2c, xy)
     ray = torch.cat([xy, torch.ones_like(zc)], dim=-1)
     coord_c = G.points_in_camera_coords(zc, ray, allBatch=True).permute(0, 3, 1, 2)
     # inverse(pose) once, through the library's own kernel, as a detached constant
-    from . import ops
     _, _, pose_c2p = ops.pose_transforms(pose_p2c.detach(), None, want_a=True)
     grid_c2p = G.coord0TOgrid1(coord_c, pose_c2p)
-    Ic_reProj = G.bilinear_sampler(IpGT, grid_c2p)
+    return zc, G.bilinear_sampler(IpGT, grid_c2p)
+
+
+def reProj_IpGT(zp_cView, pose_p2c, xy, Ic, zcGT, maskC, IpGT, fused=True):
+    """Re-projection loss; train_pytorch.py:179-211 (one crop per sample)."""
+    me = erode(maskC, 5)
+    zp = zp_cView * me
+    zc, Ic_reProj = reproject(zp, pose_p2c, xy, IpGT, fused)
     loss_zc_rms = cost_rms_mask(zcGT, zc, me)
     loss_Ic_rms = cost_rms_mask(Ic, Ic_reProj, me)
     loss_Ic_L1 = cost_L1_mask(Ic, Ic_reProj, me)

@@ -771,6 +771,85 @@ __global__ __launch_bounds__(NT) void zp_to_zc_bwd_kernel(const float* __restric
     g_zp[q] = g_zc[q] / zc_den(a, r.x, r.y);
 }
 
+// ---------------------------------------------------------------------------------------
+// Fused re-projection (the differentiated chain of reProj_IpGT, train_pytorch.py:194-202):
+//   zc    = (zp - A[2][3]) / (A[2][0] x + A[2][1] y + A[2][2])           zp_cView_to_zc, A = inverse(pose)
+//   coord = (zc x, zc y, zc, 1)                                          points_in_camera_coords(allBatch)
+//   grid  = project(T, coord), T = K A                                   coord0TOgrid1
+//   Ic    = bilinear(IpGT, grid)                                         bilinear_sampler
+// in one pass per direction, with the arithmetic of the separate operators (same device
+// functions, same rounding sequence), so the forward results are identical to composing them.
+// The composed chain moves two [B,H,W,4] point clouds (and their gradients) through HBM; this
+// one reads 12 B and writes 8 B per pixel forward, reads 20 B and writes 4 B backward, plus the
+// four-tap gathers.
+// ---------------------------------------------------------------------------------------
+template <bool FMA>
+__global__ __launch_bounds__(NT) void reproject_fwd_kernel(const float* __restrict__ zp, const float* __restrict__ xy,
+                                                           const float* __restrict__ inv, const float* __restrict__ Tm,
+                                                           const float* __restrict__ img, int H, int W, int Hs,
+                                                           int Ws, float* __restrict__ zc, float* __restrict__ out,
+                                                           float* __restrict__ grid) {
+    const int b = blockIdx.y;
+    const unsigned HW = (unsigned)(H * W);
+    const unsigned p = blockIdx.x * NT + threadIdx.x;
+    if (p >= HW) return;
+    const long base = (long)b * HW;
+    const float* a = inv + (long)b * 16;
+    const float* T = Tm + (long)b * 16;
+    const float2 r = ld_at(reinterpret_cast<const float2*>(xy) + base, p);
+    const float z = __fsub_rn(ld_at(zp + base, p), a[11]) / zc_den(a, r.x, r.y);
+    float gx, gy;
+    project_px<FMA>(T, __fmul_rn(z, r.x), __fmul_rn(z, r.y), __fmul_rn(z, 1.0f), 1.0f, gx, gy);
+    const Taps t = make_taps(gx, gy, Hs, Ws);
+    const float* im = img + (long)b * Hs * Ws;
+    const float i00 = ld_at(im, (unsigned)(t.y0 * Ws + t.x0)), i01 = ld_at(im, (unsigned)(t.y1 * Ws + t.x0));
+    const float i10 = ld_at(im, (unsigned)(t.y0 * Ws + t.x1)), i11 = ld_at(im, (unsigned)(t.y1 * Ws + t.x1));
+    st_at(zc + base, p, z);
+    st_at(out + base, p, blend(t, i00, i01, i10, i11));
+    if (grid) st_at(reinterpret_cast<float2*>(grid) + base, p, make_float2(gx, gy));
+}
+
+// g_zp = [ g_zc + (d Ic / d grid)(d grid / d coord)(d coord / d zc) g_Ic ] / zden; either incoming
+// gradient may be absent.
+template <bool FMA>
+__global__ __launch_bounds__(NT) void reproject_bwd_kernel(const float* __restrict__ g_zc, const float* __restrict__ g_out,
+                                                           const float* __restrict__ zc, const float* __restrict__ xy,
+                                                           const float* __restrict__ inv, const float* __restrict__ Tm,
+                                                           const float* __restrict__ img, int H, int W, int Hs,
+                                                           int Ws, float* __restrict__ g_zp) {
+    const int b = blockIdx.y;
+    const unsigned HW = (unsigned)(H * W);
+    const unsigned p = blockIdx.x * NT + threadIdx.x;
+    if (p >= HW) return;
+    const long base = (long)b * HW;
+    const float* a = inv + (long)b * 16;
+    const float* T = Tm + (long)b * 16;
+    const float2 r = ld_at(reinterpret_cast<const float2*>(xy) + base, p);
+    float gz = g_zc ? ld_at(g_zc + base, p) : 0.0f;
+    if (g_out) {
+        const float z = ld_at(zc + base, p);
+        const float c0 = __fmul_rn(z, r.x), c1 = __fmul_rn(z, r.y), c2 = __fmul_rn(z, 1.0f);
+        const float xu = row_dot<FMA>(T + 0, c0, c1, c2, 1.0f);
+        const float yu = row_dot<FMA>(T + 4, c0, c1, c2, 1.0f);
+        const float zu = row_dot<FMA>(T + 8, c0, c1, c2, 1.0f);
+        const float den = __fadd_rn(zu, 1e-10f);
+        const Taps t = make_taps(xu / den, yu / den, Hs, Ws);
+        const float* im = img + (long)b * Hs * Ws;
+        const float i00 = ld_at(im, (unsigned)(t.y0 * Ws + t.x0)), i01 = ld_at(im, (unsigned)(t.y1 * Ws + t.x0));
+        const float i10 = ld_at(im, (unsigned)(t.y0 * Ws + t.x1)), i11 = ld_at(im, (unsigned)(t.y1 * Ws + t.x1));
+        const float go = ld_at(g_out + base, p);
+        const float ggx = go * (t.wy0 * (i10 - i00) + t.wy1 * (i11 - i01));      // as bilinear_bwd_grid
+        const float ggy = go * (t.wx0 * (i01 - i00) + t.wx1 * (i11 - i10));
+        const float gxu = ggx / den, gyu = ggy / den;                            // as project_bwd
+        const float gzu = -(ggx * xu + ggy * yu) / (den * den);
+        const float gc0 = T[0] * gxu + T[4] * gyu + T[8] * gzu;
+        const float gc1 = T[1] * gxu + T[5] * gyu + T[9] * gzu;
+        const float gc2 = T[2] * gxu + T[6] * gyu + T[10] * gzu;
+        gz += (gc0 * r.x + gc1 * r.y) + gc2;                                     // as points_bwd
+    }
+    st_at(g_zp + base, p, gz / zc_den(a, r.x, r.y));
+}
+
 // Backward of coord_transform w.r.t. coord: with den = zu + 1e-10,
 //   g_xu = g_x/den, g_yu = g_y/den, g_zu = -(g_x*xu + g_y*yu)/den^2, g_coord = T^T g_u.
 template <int LAYOUT, bool FMA>
@@ -1063,6 +1142,40 @@ extern "C" int fc3d_zp_to_zc_bwd(void* stream, const float* g_zc, const float* x
     FC3D_LAUNCH("zp_to_zc_bwd", zp_to_zc_bwd_kernel, dim3(cdiv(HW, NT), B), dim3(NT), 0, (hipStream_t)stream, g_zc, xy, inv, HW,
                        g_zp);
     FC3D_LAUNCH_CHECK();
+    return FC3D_OK;
+}
+
+static int check_reproject(const void* xy, int B, int H, int W, int Hs, int Ws) {
+    if (int e = check_img(B, H, W)) return e;
+    if (int e = check_img(B, Hs, Ws)) return e;
+    if ((long)H * W >= (1L << 29) || (long)Hs * Ws >= (1L << 30)) return FC3D_ERANGE;   // per-image byte offsets are 32-bit
+    if (reinterpret_cast<uintptr_t>(xy) & 7u) return FC3D_EALIGN;
+    return FC3D_OK;
+}
+
+extern "C" int fc3d_reproject_fwd(void* stream, const float* zp, const float* xy, const float* inv, const float* T,
+                                  const float* img, int B, int H, int W, int Hs, int Ws, float* zc, float* out,
+                                  float* grid) {
+    if (!zp || !xy || !inv || !T || !img || !zc || !out) return FC3D_EINVAL;
+    if (int e = check_reproject(xy, B, H, W, Hs, Ws)) return e;
+    if (grid && (reinterpret_cast<uintptr_t>(grid) & 7u)) return FC3D_EALIGN;
+    const dim3 g(cdiv((long)H * W, NT), B), blk(NT);
+    hipStream_t s = (hipStream_t)stream;
+    if (use_fma(H, W)) FC3D_LAUNCH("reproject_fwd", reproject_fwd_kernel<true>, g, blk, 0, s, zp, xy, inv, T, img, H, W, Hs, Ws, zc, out, grid);
+    else FC3D_LAUNCH("reproject_fwd", reproject_fwd_kernel<false>, g, blk, 0, s, zp, xy, inv, T, img, H, W, Hs, Ws, zc, out, grid);
+    return FC3D_OK;
+}
+
+extern "C" int fc3d_reproject_bwd(void* stream, const float* g_zc, const float* g_out, const float* zc, const float* xy,
+                                  const float* inv, const float* T, const float* img, int B, int H, int W, int Hs,
+                                  int Ws, float* g_zp) {
+    if (!xy || !inv || !g_zp || (!g_zc && !g_out)) return FC3D_EINVAL;
+    if (g_out && (!zc || !T || !img)) return FC3D_EINVAL;
+    if (int e = check_reproject(xy, B, H, W, Hs, Ws)) return e;
+    const dim3 g(cdiv((long)H * W, NT), B), blk(NT);
+    hipStream_t s = (hipStream_t)stream;
+    if (use_fma(H, W)) FC3D_LAUNCH("reproject_bwd", reproject_bwd_kernel<true>, g, blk, 0, s, g_zc, g_out, zc, xy, inv, T, img, H, W, Hs, Ws, g_zp);
+    else FC3D_LAUNCH("reproject_bwd", reproject_bwd_kernel<false>, g, blk, 0, s, g_zc, g_out, zc, xy, inv, T, img, H, W, Hs, Ws, g_zp);
     return FC3D_OK;
 }
 

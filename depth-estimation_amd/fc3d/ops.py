@@ -400,3 +400,49 @@ class ZpToZcFn(torch.autograd.Function):
             _check(_lib.fc3d_zp_to_zc_bwd(_stream(), g.data_ptr(), r.data_ptr(), inv.data_ptr(), B, H, W,
                                           gz.data_ptr()), "fc3d_zp_to_zc_bwd")
         return gz, None, None
+
+
+class ReprojectFn(torch.autograd.Function):
+    """zp_cView -> (zc, pattern sampled at the re-projected position): the differentiated chain
+    of reProj_IpGT (train_pytorch.py:194-202) in one kernel per direction.  inv = inverse(pose),
+    T = K @ inverse(pose); gradient w.r.t. zp only."""
+
+    @staticmethod
+    def forward(ctx, zp, xy, inv, T, img):
+        dev = _need_gpu(zp, xy, inv, T, img)
+        B, H, W, _ = zp.shape
+        if (tuple(zp.shape) != (B, H, W, 1) or tuple(xy.shape) != (B, H, W, 2) or img.dim() != 4
+                or img.shape[0] != B or img.shape[3] != 1
+                or tuple(inv.shape) != (B, 4, 4) or tuple(T.shape) != (B, 4, 4)):
+            raise RuntimeError(f"reproject: zp {tuple(zp.shape)}, xy {tuple(xy.shape)}, img {tuple(img.shape)}, "
+                               f"inverse pose {tuple(inv.shape)}, transform {tuple(T.shape)}")
+        z, r, a, t, im = _dense(zp), _dense(xy), _dense(inv), _dense(T), _dense(img)
+        zc = torch.empty_like(z)
+        out = torch.empty_like(z)
+        with _on_device(dev):
+            _check(_lib.fc3d_reproject_fwd(_stream(), z.data_ptr(), r.data_ptr(), a.data_ptr(), t.data_ptr(),
+                                           im.data_ptr(), B, H, W, im.shape[1], im.shape[2], zc.data_ptr(),
+                                           out.data_ptr(), None),
+                   "fc3d_reproject_fwd")
+        ctx.save_for_backward(zc, r, a, t, im)
+        ctx.set_materialize_grads(False)
+        return zc, out
+
+    @staticmethod
+    def backward(ctx, g_zc, g_out):
+        if any(ctx.needs_input_grad[1:]):
+            raise NotImplementedError("reproject: only the gradient w.r.t. zp_cView is implemented")
+        if g_zc is None and g_out is None:
+            return None, None, None, None, None
+        zc, r, a, t, im = ctx.saved_tensors
+        B, H, W, _ = zc.shape
+        gz = _dense(g_zc) if g_zc is not None else None
+        go = _dense(g_out) if g_out is not None else None
+        gp = torch.empty_like(zc)
+        with _on_device(zc.device):
+            _check(_lib.fc3d_reproject_bwd(_stream(), gz.data_ptr() if gz is not None else None,
+                                           go.data_ptr() if go is not None else None, zc.data_ptr(), r.data_ptr(),
+                                           a.data_ptr(), t.data_ptr(), im.data_ptr(), B, H, W, im.shape[1],
+                                           im.shape[2], gp.data_ptr()),
+                   "fc3d_reproject_bwd")
+        return gp, None, None, None, None

@@ -178,6 +178,20 @@ int fc3d_zp_to_zc_fwd(void *stream, const float *zp, const float *xy, const floa
 int fc3d_zp_to_zc_bwd(void *stream, const float *g_zc, const float *xy, const float *inv, int B, int H, int W,
                       float *g_zp);
 
+/* The differentiated chain of reProj_IpGT, train_pytorch.py:194-202, in one pass:
+ * zc = zp_cView_to_zc(zp, pose, xy) (geometry_pytorch.py:284-308), scene points
+ * (zc*x, zc*y, zc, 1) (:44-65, allBatch), grid = coord0TOgrid1(points, inverse(pose))
+ * (:93-106), out = bilinear_sampler(img, grid) (:109-177).  inv = inverse(pose),
+ * T = K*inverse(pose), both [B][16] (fc3d_pose_transforms); xy [B][H][W][2];
+ * zp, zc, out [B][H][W]; img [B][Hs][Ws]; grid [B][H][W][2] may be NULL.  Results are those of the
+ * separate entry points applied in sequence.  Backward w.r.t. zp from the gradients of
+ * zc and out (either may be NULL); img, xy and the pose carry no gradient here.        */
+int fc3d_reproject_fwd(void *stream, const float *zp, const float *xy, const float *inv, const float *T,
+                       const float *img, int B, int H, int W, int Hs, int Ws, float *zc, float *out, float *grid);
+int fc3d_reproject_bwd(void *stream, const float *g_zc, const float *g_out, const float *zc, const float *xy,
+                       const float *inv, const float *T, const float *img, int B, int H, int W, int Hs, int Ws,
+                       float *g_zp);
+
 /* ------------------------------------------------------------------------ */
 /* optional per-kernel timing (no counterpart in the reference, which has no   */
 /* profiling hooks): while enabled every kernel launch of this library is       */

@@ -384,6 +384,55 @@ def test_reproj_chain(mods, golden, monkeypatch):
     assert rel_err(zp.grad.cpu().numpy(), g["grad_zp"]) < TOL
 
 
+def test_reproject_fused(mods, golden, monkeypatch):
+    """The one-kernel re-projection chain: identical forward results to composing the operators,
+    the fixture's values and gradient, and the right gradient when only one output is used."""
+    g = golden("g7_reproj")
+    G, ops = mods["G"], mods["ops"]
+    monkeypatch.setattr(G, "get_intrinsic", patched_K(float(g["cx"]), float(g["cy"])))
+    xy, pose, img = dev(g["xy"]), dev(g["pose"]), dev(g["IpGT"])
+    B = xy.shape[0]
+    inv = dev(g["pose_c2p"])                                           # the reference's own inverse
+    K = G.get_intrinsic(B)
+    T, _, _ = ops.pose_transforms(inv, K, want_fwd=True)               # K @ inverse(pose)
+    # composed
+    zp1 = dev(g["zp"]).requires_grad_(True)
+    zc1 = G.zp_cView_to_zc(zp1, pose, xy)
+    ray = torch.cat([xy, torch.ones_like(zc1)], dim=-1)
+    grid1 = G.coord0TOgrid1(G.points_in_camera_coords(zc1, ray, allBatch=True).permute(0, 3, 1, 2), inv)
+    Ic1 = G.bilinear_sampler(img, grid1)
+    # fused, fed the same inverse
+    zp2 = dev(g["zp"]).requires_grad_(True)
+    zc2, Ic2 = ops.ReprojectFn.apply(zp2, xy, inv, T, img)
+    assert rel_err(zc2.detach().cpu().numpy(), g["zc"]) < 1e-6 and rel_err(Ic2.detach().cpu().numpy(), g["Ic"]) < TOL
+    # zc through the library's own fp64 inverse differs from the fixture's LAPACK inverse in the last bit at most
+    assert rel_err(zc2.detach().cpu().numpy(), zc1.detach().cpu().numpy()) < 1e-6
+    assert rel_err(Ic2.detach().cpu().numpy(), Ic1.detach().cpu().numpy()) < TOL
+    ((Ic2 * dev(g["g_ic"])).sum() + (zc2 * dev(g["g_zc"])).sum()).backward()
+    assert rel_err(zp2.grad.cpu().numpy(), g["grad_zp"]) < TOL
+    for use in ("zc", "Ic"):
+        a = dev(g["zp"]).requires_grad_(True)
+        b = dev(g["zp"]).requires_grad_(True)
+        zca, Ica = ops.ReprojectFn.apply(a, xy, inv, T, img)
+        zcb = G.zp_cView_to_zc(b, pose, xy)
+        rayb = torch.cat([xy, torch.ones_like(zcb)], dim=-1)
+        Icb = G.bilinear_sampler(img, G.coord0TOgrid1(
+            G.points_in_camera_coords(zcb, rayb, allBatch=True).permute(0, 3, 1, 2), inv))
+        if use == "zc":
+            (zca * dev(g["g_zc"])).sum().backward()
+            (zcb * dev(g["g_zc"])).sum().backward()
+        else:
+            (Ica * dev(g["g_ic"])).sum().backward()
+            (Icb * dev(g["g_ic"])).sum().backward()
+        assert rel_err(a.grad.cpu().numpy(), b.grad.cpu().numpy()) < TOL, use
+    # same inverse for both paths => identical bits forward
+    from fc3d import capture
+    zp3 = dev(g["zp"])
+    zf, If = capture.reproject(zp3, pose, xy, img, fused=True)
+    zs, Is = capture.reproject(zp3, pose, xy, img, fused=False)
+    assert torch.equal(zf, zs) and torch.equal(If, Is)
+
+
 def test_errors_are_loud(mods):
     G, O = mods["G"], mods["O"]
     with pytest.raises(RuntimeError):
