@@ -25,7 +25,9 @@ def test_cabi_exports_every_declared_symbol():
     assert lib.fc3d_status_string(-1).decode().startswith("invalid")
     # argument validation happens before any device work
     assert lib.fc3d_visible_mask(None, None, 1, 4, 4, 0, None, None) == -1
-    assert lib.fc3d_code_pattern_fwd_workspace(32, 512, 512) == 32 * 768 * 8   # 12 strips x 64 row blocks
+    # one 64-bit key per tile/strip of whichever kernel family has the most of them at this size:
+    # 8 x 128 for the 64-column x 4-row wavefronts of the large-PSF kernels
+    assert lib.fc3d_code_pattern_fwd_workspace(32, 512, 512) == 32 * 1024 * 8
     assert lib.fc3d_bilinear_bwd_img_workspace(2, 64, 96, 1, 64, 96) == 2 * 24 * (16 + 1024 * 4)
 
 
