@@ -8,12 +8,12 @@
 // Three kernel families, picked by PSF size:
 //   rolling-row (3x3, 5x5, 7x7; near the end of this file): one pixel column per lane, column
 //       neighbours through wavefront shifts, PSF weights of the lane's layer in registers;
-//   wide LDS tiles (other odd widths up to 33, images at least 192 wide): 256x8 tiles, pattern
-//       and halo staged in LDS, 4x2 outputs per lane;
-//   generic 64x16 LDS tiles (everything else, and is_conv_psf=False).
-// In the LDS families the backward pass first sums g*out per image (deterministic two-level
-// sum), then evaluates the transposed convolution in gather form: every output pixel walks its
-// K x K neighbours p and uses the PSF of *p's* layer.
+//   layer sweep (9x9 ... 33x33 odd; after the rolling-row kernels): 64 columns x 4 rows per
+//       wavefront, input tile in LDS, one depth layer at a time with the PSF in scalar registers;
+//   generic 64x16 LDS tiles (everything else: even or non-square PSFs, 1x1, is_conv_psf=False):
+//       the backward pass first sums g*out per image (deterministic two-level sum), then
+//       evaluates the transposed convolution in gather form: every output pixel walks its K x K
+//       neighbours p and uses the PSF of *p's* layer.
 #include "fc3d_common.h"
 #include <type_traits>
 
@@ -448,39 +448,7 @@ __global__ __launch_bounds__(NT) void code_pattern_bwd_kernel(
     }
 }
 
-// ---------------------------------------------------------------------------------------
-// Wide-tile kernels: kernel width known at compile time, tile = 256 x 8 pixels.
-//
-// A wavefront owns whole 256-pixel row pieces, so global traffic moves as 1-KiB contiguous
-// runs (a 64-pixel-wide tile fetched 256-byte scraps of many DRAM rows and ran at a fifth of
-// the streaming rate) and the 16-byte LDS reads of a wavefront sweep one row: conflict-free.
-// Every lane produces 4 x 2 outputs (two vertically adjacent rows share K-1 of their K input
-// rows, which are read from LDS once), keeping one KW+3-float row segment and one zero-padded
-// PSF row in registers at a time.
-// ---------------------------------------------------------------------------------------
-constexpr int WX = 256, WY = 8;
-
-template <int KW>
-struct Wide {
-    static constexpr int KWP = (KW + 3) & ~3;          // PSF row padded to whole float4s
-    static constexpr int NSEG = (KW + 3 + 3) / 4;      // float4s covering the KW+3 pattern floats of 4 outputs
-    static constexpr int HALO = 4 * NSEG - 4;          // staged columns beyond the 256 body columns
-    static constexpr int RS = WX + 4 * NSEG;           // LDS row stride in floats (multiple of 4)
-};
-
-// Copies PSF layers [l0, l0+nl) into LDS as [layer][Kh][KWP] (zero padded rows).
-template <int KW>
-__device__ __forceinline__ void stage_psfs(float* __restrict__ wts, const float* __restrict__ psf, int l0, int nl,
-                                           int Kh) {
-    constexpr int KWP = Wide<KW>::KWP;
-    const int n = nl * Kh * KWP;
-    const float* src = psf + (long)l0 * Kh * KW;
-    for (int i = threadIdx.x; i < n; i += NT) {
-        const int row = i / KWP, dx = i - row * KWP;
-        wts[i] = dx < KW ? src[row * KW + dx] : 0.0f;
-    }
-}
-
+// N floats (a multiple of 4) from a 16-byte aligned LDS address, as 16-byte reads.
 template <int N>
 __device__ __forceinline__ void lds_read4(const float* p, float (&dst)[N]) {
     const float4* q = reinterpret_cast<const float4*>(p);
@@ -488,414 +456,6 @@ __device__ __forceinline__ void lds_read4(const float* p, float (&dst)[N]) {
     for (int j = 0; j < N / 4; ++j) {
         const float4 v = q[j];
         dst[4 * j] = v.x; dst[4 * j + 1] = v.y; dst[4 * j + 2] = v.z; dst[4 * j + 3] = v.w;
-    }
-}
-
-template <int KW>
-__global__ __launch_bounds__(NT) void code_pattern_fwd_wide_kernel(
-    const float* __restrict__ pat0, long sb, long sh, long sw, const float* __restrict__ z,
-    const float* __restrict__ psf, int H, int W, int Kh, int stage_all, int cap_layers, int vec,
-    fc3d_layer_grid lg, float* __restrict__ raw, uint8_t* __restrict__ layer_u8,
-    unsigned long long* __restrict__ tilekey) {
-    constexpr int KWP = Wide<KW>::KWP, NSEG = Wide<KW>::NSEG, HALO = Wide<KW>::HALO, RS = Wide<KW>::RS;
-    extern __shared__ float smem[];
-    __shared__ int s_lmin, s_lmax, s_qn;
-    __shared__ unsigned long long s_key[NT / 64];
-
-    const int b = blockIdx.z;
-    const int x0 = blockIdx.x * WX, y0 = blockIdx.y * WY;
-    if (threadIdx.x == 0) s_qn = 0;
-    const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
-    const int x = x0 + 4 * tx;
-    const long img = (long)b * H * W;
-    const int th = WY + Kh - 1;
-    float* tile = smem;
-    float* wts = smem + th * RS;
-
-    // -- pattern tile + halo, zero 'same' padding
-    const int padh = (Kh - 1) / 2, padw = (KW - 1) / 2;
-    const float* pimg = pat0 + (long)b * sb;
-    // Loads are unconditional from clamped (always valid) addresses and issued eight rows at a time
-    // before the first use, so a wavefront pays one memory latency per batch, not one per row.
-    {
-        const int gx = x0 - padw + tid;
-        const bool colok = gx >= 0 && gx < W;
-        const long xoff = (long)min(max(gx, 0), W - 1) * sw;
-        for (int r0 = 0; r0 < th; r0 += 8) {
-            float v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int gy = y0 - padh + r0 + u;
-                v[u] = pimg[(long)min(max(gy, 0), H - 1) * sh + xoff];
-                if (!(colok && gy >= 0 && gy < H)) v[u] = 0.0f;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (r0 + u < th) tile[(r0 + u) * RS + tid] = v[u];
-        }
-    }
-    if constexpr (HALO > 0) {
-        for (int i = tid; i < HALO * th; i += NT) {
-            const int r = i / HALO, c = WX + (i - r * HALO);
-            const int gy = y0 - padh + r, gx = x0 - padw + c;
-            float v = pimg[(long)min(max(gy, 0), H - 1) * sh + (long)min(max(gx, 0), W - 1) * sw];
-            if (!(gy >= 0 && gy < H && gx >= 0 && gx < W)) v = 0.0f;
-            tile[r * RS + c] = v;
-        }
-    }
-
-    // -- depth layers of my 4 x 2 pixels (rows y0 + 2*ty + o)
-    int lay[2][4];
-    bool inb[2][4];
-    int lmin = 1 << 30, lmax = -1;
-#pragma unroll
-    for (int o = 0; o < 2; ++o) {
-        const int y = y0 + 2 * ty + o;
-        float zv[4] = {1.0f, 1.0f, 1.0f, 1.0f};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) inb[o][i] = (y < H) && (x + i < W);
-        if (vec) {
-            if (inb[o][0]) {
-                const float4 v = *reinterpret_cast<const float4*>(z + img + (long)y * W + x);
-                zv[0] = v.x; zv[1] = v.y; zv[2] = v.z; zv[3] = v.w;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (inb[o][i]) zv[i] = z[img + (long)y * W + x + i];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            lay[o][i] = inb[o][i] ? layer_of(zv[i], lg) : -1;
-            if (lay[o][i] >= 0) {
-                lmin = min(lmin, lay[o][i]);
-                lmax = max(lmax, lay[o][i]);
-            }
-        }
-    }
-    int bl0 = 0, nl = lg.n_layers;
-    if (!stage_all) {
-        block_minmax(lmin, lmax, &s_lmin, &s_lmax);
-        bl0 = s_lmin;
-        nl = (s_lmax >= bl0) ? min(s_lmax - bl0 + 1, cap_layers) : 0;
-    }
-    stage_psfs<KW>(wts, psf, bl0, nl, Kh);
-    __syncthreads();
-
-    float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    if (stage_all) {
-        // A wavefront's 256-pixel row crosses several depth layers, but a lane's 4 x 2 pixels almost
-        // always share one.  Every lane blurs all its pixels with the PSF of its first valid pixel's
-        // layer (PSF rows in registers, no per-pixel branches); the few pixels of another layer are
-        // queued in LDS and redone one per thread afterwards.  Both passes add taps in the same
-        // order (dy, then dx ascending), so a pixel's value does not depend on the pass that made it.
-        uint32_t* q = reinterpret_cast<uint32_t*>(wts + lg.n_layers * Kh * KWP);
-        int lp = -1, cnt = 0;
-#pragma unroll
-        for (int o = 0; o < 2; ++o)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (lp < 0 && lay[o][i] >= 0) lp = lay[o][i];
-#pragma unroll
-        for (int o = 0; o < 2; ++o)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) cnt += (lay[o][i] >= 0 && lay[o][i] != lp) ? 1 : 0;
-        int slot = 0;
-        if (cnt) {
-            slot = atomicAdd(&s_qn, cnt);
-            int j = 0;
-#pragma unroll
-            for (int o = 0; o < 2; ++o)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (lay[o][i] >= 0 && lay[o][i] != lp)
-                        q[slot + j++] = ((uint32_t)(2 * ty + o) << 16) | ((uint32_t)(4 * tx + i) << 8) | (uint32_t)lay[o][i];
-        }
-        if (lp >= 0) {
-            const float* wl = wts + lp * Kh * KWP;
-            // input row rr of the lane's 2-row strip feeds output row 0 with dy = rr, row 1 with dy = rr-1
-            for (int rr = 0; rr <= Kh; ++rr) {
-                float seg[4 * NSEG];
-                lds_read4<4 * NSEG>(tile + (2 * ty + rr) * RS + 4 * tx, seg);
-#pragma unroll
-                for (int o = 0; o < 2; ++o) {
-                    const int dy = rr - o;
-                    if (dy < 0 || dy >= Kh) continue;
-                    float w[KWP];
-                    lds_read4<KWP>(wl + dy * KWP, w);
-#pragma unroll
-                    for (int dx = 0; dx < KW; ++dx)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) acc[o][i] = fmaf(w[dx], seg[dx + i], acc[o][i]);
-                }
-            }
-        }
-        __syncthreads();
-        const int qn = s_qn;
-        for (int e = tid; e < qn; e += NT) {
-            const uint32_t v = q[e];
-            const int row = (int)(v >> 16), col = (int)((v >> 8) & 255u), l = (int)(v & 255u);
-            const float* wl = wts + l * Kh * KWP;
-            float a = 0.0f;
-            for (int dy = 0; dy < Kh; ++dy) {
-                const float* tr = tile + (row + dy) * RS + col;
-                const float* wr = wl + dy * KWP;
-#pragma unroll
-                for (int dx = 0; dx < KW; ++dx) a = fmaf(wr[dx], tr[dx], a);
-            }
-            q[e] = __float_as_uint(a);
-        }
-        __syncthreads();
-        if (cnt) {
-            int j = 0;
-#pragma unroll
-            for (int o = 0; o < 2; ++o)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (lay[o][i] >= 0 && lay[o][i] != lp) acc[o][i] = __uint_as_float(q[slot + j++]);
-        }
-    } else {
-    bool uni[2], any[2];
-#pragma unroll
-    for (int o = 0; o < 2; ++o) {
-        const int l0 = lay[o][0];
-        any[o] = (lay[o][0] >= 0) | (lay[o][1] >= 0) | (lay[o][2] >= 0) | (lay[o][3] >= 0);
-        uni[o] = (l0 >= bl0) && (l0 - bl0 < nl) && (lay[o][1] == l0) && (lay[o][2] == l0) && (lay[o][3] == l0);
-    }
-    // input row rr of the lane's 2-row strip feeds output row 0 with dy = rr and output row 1 with dy = rr-1
-    for (int rr = 0; rr <= Kh; ++rr) {
-        float seg[4 * NSEG];
-        lds_read4<4 * NSEG>(tile + (2 * ty + rr) * RS + 4 * tx, seg);
-#pragma unroll
-        for (int o = 0; o < 2; ++o) {
-            const int dy = rr - o;
-            if (dy < 0 || dy >= Kh || !any[o]) continue;
-            if (uni[o]) {
-                float w[KWP];
-                lds_read4<KWP>(wts + ((lay[o][0] - bl0) * Kh + dy) * KWP, w);
-#pragma unroll
-                for (int dx = 0; dx < KW; ++dx)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[o][i] = fmaf(w[dx], seg[dx + i], acc[o][i]);
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int l = lay[o][i];
-                    if (l < 0) continue;
-                    if (l >= bl0 && l - bl0 < nl) {
-                        float w[KWP];
-                        lds_read4<KWP>(wts + ((l - bl0) * Kh + dy) * KWP, w);
-#pragma unroll
-                        for (int dx = 0; dx < KW; ++dx) acc[o][i] = fmaf(w[dx], seg[dx + i], acc[o][i]);
-                    } else {   // tile spans more layers than fit in LDS: read the row from global memory
-                        const float* wr = psf + ((long)l * Kh + dy) * KW;
-#pragma unroll
-                        for (int dx = 0; dx < KW; ++dx) acc[o][i] = fmaf(wr[dx], seg[dx + i], acc[o][i]);
-                    }
-                }
-            }
-        }
-    }
-
-    }
-
-    // -- gate by the layer mask (a multiply, so a non-finite blur still poisons the pixel as conv*0
-    //    does in the reference), store, publish the tile's max key
-    unsigned long long key = 0;
-#pragma unroll
-    for (int o = 0; o < 2; ++o) {
-        const int y = y0 + 2 * ty + o;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            acc[o][i] = acc[o][i] * (lay[o][i] >= 0 ? 1.0f : 0.0f);
-            if (inb[o][i]) {
-                const uint32_t pos = 0xffffffffu - (uint32_t)((x + i) * H + y);   // first w, then first h
-                const unsigned long long k = ((unsigned long long)float_to_key(acc[o][i]) << 32) | pos;
-                key = k > key ? k : key;
-            }
-        }
-        if (vec) {
-            if (inb[o][0]) {
-                *reinterpret_cast<float4*>(raw + img + (long)y * W + x) =
-                    make_float4(acc[o][0], acc[o][1], acc[o][2], acc[o][3]);
-                if (layer_u8)
-                    *reinterpret_cast<uchar4*>(layer_u8 + img + (long)y * W + x) = make_uchar4(
-                        (uint8_t)lay[o][0], (uint8_t)lay[o][1], (uint8_t)lay[o][2], (uint8_t)lay[o][3]);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (inb[o][i]) {
-                    raw[img + (long)y * W + x + i] = acc[o][i];
-                    if (layer_u8) layer_u8[img + (long)y * W + x + i] = (uint8_t)lay[o][i];
-                }
-        }
-    }
-    key = wave_max(key);
-    if ((tid & 63) == 0) s_key[tid >> 6] = key;
-    __syncthreads();
-    if (tid == 0) {
-        unsigned long long k = s_key[0];
-#pragma unroll
-        for (int i = 1; i < NT / 64; ++i) k = s_key[i] > k ? s_key[i] : k;
-        tilekey[(long)b * gridDim.x * gridDim.y + blockIdx.y * gridDim.x + blockIdx.x] = k;
-    }
-}
-
-template <int KW>
-__global__ __launch_bounds__(NT) void code_pattern_bwd_wide_kernel(
-    const float* __restrict__ g, const uint8_t* __restrict__ layer_u8, const float* __restrict__ max_in,
-    const int* __restrict__ argmax_in, const float* __restrict__ partial, int npartial,
-    const float* __restrict__ psf, int H, int W, int L, int Kh, int stage_all, int cap_layers, int vec,
-    float* __restrict__ g_pat0) {
-    constexpr int KWP = Wide<KW>::KWP, NSEG = Wide<KW>::NSEG, HALO = Wide<KW>::HALO, RS = Wide<KW>::RS;
-    extern __shared__ float smem[];
-    __shared__ int s_lmin, s_lmax;
-    __shared__ float s_red[NT / 64];
-
-    const int b = blockIdx.z;
-    const int x0 = blockIdx.x * WX, y0 = blockIdx.y * WY;
-    const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
-    const int x = x0 + 4 * tx;
-    const long img = (long)b * H * W;
-    const int th = WY + Kh - 1;
-    float* tile = smem;                                                   // graw with halo
-    uint8_t* ltile = reinterpret_cast<uint8_t*>(smem + th * RS);          // layer of every staged pixel
-    float* wts = smem + th * RS + th * (RS / 4);
-
-    float s = 0.0f;
-    for (int i = tid; i < npartial; i += NT) s += partial[(long)b * npartial + i];
-    const float S = block_sum(s, s_red);
-    const float den = max_in[b] + 1e-10f;
-    const float corr = S / den;       // d/d(max) of sum(g * raw/den) = -sum(g*out)/den
-    const int am = argmax_in[b];
-
-    const int padh = (Kh - 1) / 2, padw = (KW - 1) / 2;
-    const int hb = Kh - 1 - padh, wb = KW - 1 - padw;     // halo before the tile (rows / columns)
-    int lmin = 1 << 30, lmax = -1;
-    // unconditional loads from clamped addresses, batched ahead of their first use (see forward)
-    auto fetch = [&](int r, int c, float& gv, uint8_t& l, bool& ok, long& p) {
-        const int gy = y0 - hb + r, gx = x0 - wb + c;
-        ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
-        p = (long)min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1);
-        gv = g[img + p];
-        l = layer_u8[img + p];
-    };
-    auto put = [&](int r, int c, float gv, uint8_t l, bool ok, long p) {
-        float v = 0.0f;
-        if (!ok) l = 255;
-        if (l != 255) {
-            v = gv / den;
-            if ((int)p == am) v -= corr;
-            lmin = min(lmin, (int)l);
-            lmax = max(lmax, (int)l);
-        }
-        tile[r * RS + c] = v;
-        ltile[r * RS + c] = l;
-    };
-    for (int r0 = 0; r0 < th; r0 += 8) {
-        float gv[8];
-        uint8_t l[8];
-        bool ok[8];
-        long p[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) fetch(r0 + u, tid, gv[u], l[u], ok[u], p[u]);
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (r0 + u < th) put(r0 + u, tid, gv[u], l[u], ok[u], p[u]);
-    }
-    if constexpr (HALO > 0) {
-        for (int i = tid; i < HALO * th; i += NT) {
-            const int r = i / HALO, c = WX + (i - r * HALO);
-            float gv;
-            uint8_t l;
-            bool ok;
-            long p;
-            fetch(r, c, gv, l, ok, p);
-            put(r, c, gv, l, ok, p);
-        }
-    }
-    int bl0 = 0, nl = L;
-    if (!stage_all) {
-        block_minmax(lmin, lmax, &s_lmin, &s_lmax);
-        bl0 = s_lmin;
-        nl = (s_lmax >= bl0) ? min(s_lmax - bl0 + 1, cap_layers) : 0;
-    }
-    stage_psfs<KW>(wts, psf, bl0, nl, Kh);
-    __syncthreads();
-
-    // g_pat0[q] = sum_d PSF[layer(p)][d] * graw[p],  p = q - d + pad.  Source pixel p of output row o
-    // and tap dy sits in staged row 2*ty + o + (Kh-1-dy), staged column 4*tx + i + (KW-1-dx): a
-    // correlation of the row segment with the flipped PSF row of the layer each *source* pixel is in.
-    float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    for (int rr = 0; rr <= Kh; ++rr) {
-        const int r = 2 * ty + rr;
-        float seg[4 * NSEG];
-        uint32_t lw[NSEG];
-        lds_read4<4 * NSEG>(tile + r * RS + 4 * tx, seg);
-        const uint32_t* lp = reinterpret_cast<const uint32_t*>(ltile + r * RS + 4 * tx);
-#pragma unroll
-        for (int j = 0; j < NSEG; ++j) lw[j] = lp[j];
-        const uint32_t l0 = lw[0] & 0xffu;
-        const uint32_t rep = l0 * 0x01010101u;
-        bool same = (l0 != 255u) && ((int)l0 >= bl0) && ((int)l0 - bl0 < nl);
-#pragma unroll
-        for (int j = 0; j < NSEG; ++j) {
-            constexpr int used = KW + 3;                        // only the first KW+3 bytes matter
-            const int nb = used - 4 * j >= 4 ? 4 : used - 4 * j;
-            const uint32_t msk = nb >= 4 ? 0xffffffffu : ((1u << (8 * nb)) - 1u);
-            same = same && (((lw[j] ^ rep) & msk) == 0u);
-        }
-#pragma unroll
-        for (int o = 0; o < 2; ++o) {
-            const int dy = Kh - 1 - (rr - o);                   // staged row r = 2*ty + o + (Kh-1-dy)
-            if (dy < 0 || dy >= Kh) continue;
-            if (same) {
-                float w[KWP];
-                lds_read4<KWP>(wts + (((int)l0 - bl0) * Kh + dy) * KWP, w);
-#pragma unroll
-                for (int ee = 0; ee < KW; ++ee)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[o][i] = fmaf(w[KW - 1 - ee], seg[i + ee], acc[o][i]);
-            } else {
-#pragma unroll
-                for (int e = 0; e < KW + 3; ++e) {
-                    const int l = (int)((lw[e >> 2] >> (8 * (e & 3))) & 0xffu);
-                    if (l == 255) continue;
-                    // two explicit branches: one pointer that may be LDS or global would compile to
-                    // flat loads, which crawl through the vector-memory path even for LDS addresses
-                    if (stage_all || ((l >= bl0) && (l - bl0 < nl))) {
-                        const float* wr = wts + ((l - bl0) * Kh + dy) * KWP;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int ee = e - i;
-                            if (ee >= 0 && ee < KW) acc[o][i] = fmaf(wr[KW - 1 - ee], seg[e], acc[o][i]);
-                        }
-                    } else {
-                        const float* wr = psf + ((long)l * Kh + dy) * KW;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int ee = e - i;
-                            if (ee >= 0 && ee < KW) acc[o][i] = fmaf(wr[KW - 1 - ee], seg[e], acc[o][i]);
-                        }
-                    }
-                }
-            }
-        }
-    }
-    
-#pragma unroll
-    for (int o = 0; o < 2; ++o) {
-        const int y = y0 + 2 * ty + o;
-        if (vec) {
-            if (y < H && x < W)
-                *reinterpret_cast<float4*>(g_pat0 + img + (long)y * W + x) =
-                    make_float4(acc[o][0], acc[o][1], acc[o][2], acc[o][3]);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (y < H && x + i < W) g_pat0[img + (long)y * W + x + i] = acc[o][i];
-        }
     }
 }
 
@@ -1423,34 +983,14 @@ constexpr int kSweepRows = FC3D_SWEEP_ROWS;                     // output rows p
 constexpr int kRollRows = FC3D_ROLL_ROWS;         // output rows per strip of the rolling-row kernels: forward,
 constexpr int kRollRowsBwd = FC3D_ROLL_ROWS_BWD;  // backward
 
-// LDS plan of the wide kernels: returns bytes (0 = does not fit), and through the pointers whether
-// all L layers are staged (no per-tile layer range needed) and how many layers the weight area holds.
-constexpr int kWideLdsBudget = 96 * 1024;
-template <int KW>
-static size_t wide_lds_plan(int Kh, int L, bool bwd, int* stage_all, int* cap) {
-    const int th = WY + Kh - 1;
-    const size_t tile_b = (size_t)th * Wide<KW>::RS * 4 + (bwd ? (size_t)th * Wide<KW>::RS : 0);
-    const size_t per_layer = (size_t)Kh * Wide<KW>::KWP * 4;
-    if (tile_b + per_layer > (size_t)kWideLdsBudget) return 0;
-    long c = (long)((kWideLdsBudget - tile_b) / per_layer);
-    if (c > L) c = L;
-    *stage_all = (c == L) && ((size_t)L * per_layer <= 16 * 1024);
-    *cap = (int)c;
-    // With every layer staged the forward kernel keeps a 2048-entry redo queue behind the weights.
-    // (The same scheme was tried for the backward kernel and lost: there an output must be redone
-    // whenever ANY source of its K x K footprint lies in another layer, ~40% of them: 103 vs 74 us.)
-    return tile_b + (size_t)c * per_layer + ((*stage_all && !bwd) ? (size_t)WX * WY * 4 : 0);
-}
-
+constexpr int kBigLdsBudget = 96 * 1024;      // dynamic LDS a kernel may be allowed beyond the 48 KiB default
 template <typename K>
 static int allow_big_lds(K kernel, size_t bytes) {
     if (bytes <= 48 * 1024) return FC3D_OK;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWideLdsBudget);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBigLdsBudget);
     return e == hipSuccess ? FC3D_OK : (int)e;
 }
-
-#define FC3D_FOR_WIDE_KW(X) X(1) X(3) X(5) X(7) X(9) X(11) X(13) X(15) X(17) X(19) X(21) X(23) X(25) X(27) X(29) X(31) X(33)
 
 static int layer_capacity(int Kh, int Kw, int L, bool with_layer_tile, size_t* lds_bytes) {
     const TileGeom tg = tile_geom(Kh, Kw);
@@ -1469,11 +1009,10 @@ using namespace fc3d;
 
 extern "C" size_t fc3d_code_pattern_fwd_workspace(int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0) return 0;
-    const long a = (long)cdiv(W, TX) * cdiv(H, TY), w = (long)cdiv(W, WX) * cdiv(H, WY);
+    const long a = (long)cdiv(W, TX) * cdiv(H, TY);
     const long r = (long)cdiv(cdiv(W, Roll<7>::SW), NT / 64) * (NT / 64) * cdiv(H, kRollRows);
     const long sw = (long)cdiv(W, 64) * cdiv(H, kSweepRows);
-    long m = a > w ? a : w;
-    m = r > m ? r : m;
+    long m = a > r ? a : r;
     m = sw > m ? sw : m;
     return (size_t)B * m * sizeof(unsigned long long);
 }
@@ -1537,22 +1076,6 @@ extern "C" int fc3d_code_pattern_fwd(void* stream, const float* pat0, int64_t pa
     }
         FC3D_FOR_SWEEP_K(FC3D_FWD_SWEEP_CASE)
 #undef FC3D_FWD_SWEEP_CASE
-    }
-    if (conv_flag && W >= 192) {
-        int stage_all = 0, fcap = 0;
-        size_t flds = 0;
-        const dim3 gw(cdiv(W, WX), cdiv(H, WY), B);
-#define FC3D_FWD_CASE(KWV)                                                                                      \
-    if (Kw == KWV && (flds = wide_lds_plan<KWV>(Kh, grid.n_layers, false, &stage_all, &fcap)) != 0) {            \
-        if (int e = allow_big_lds(code_pattern_fwd_wide_kernel<KWV>, flds)) return e;                           \
-        *keys_per_image = (int)(gw.x * gw.y);                                                                   \
-        FC3D_LAUNCH("code_pattern_fwd", code_pattern_fwd_wide_kernel<KWV>, gw, blk, flds, s, pat0,              \
-                    (long)pat_sb, (long)pat_sh, (long)pat_sw, z, psf, H, W, Kh, stage_all, fcap, (int)vec,      \
-                    grid, raw_out, layer_u8, (unsigned long long*)tilekey_u64);                                 \
-        return FC3D_OK;                                                                                         \
-    }
-        FC3D_FOR_WIDE_KW(FC3D_FWD_CASE)
-#undef FC3D_FWD_CASE
     }
     auto k = vec ? code_pattern_fwd_kernel<true> : code_pattern_fwd_kernel<false>;
     *keys_per_image = (int)(g.x * g.y);
@@ -1628,20 +1151,6 @@ extern "C" int fc3d_code_pattern_bwd(void* stream, const float* g_out, const flo
     auto kr = rvec ? code_pattern_bwd_reduce_kernel<true> : code_pattern_bwd_reduce_kernel<false>;
     FC3D_LAUNCH("code_pattern_bwd_reduce", kr, dim3(nred, B), dim3(NT), 0, s, g_out, out, HW, partial);
     const bool vec = (W % 4 == 0) && aligned16(g_pat0);
-    if (conv_flag && W >= 192) {
-        int stage_all = 0, fcap = 0;
-        size_t flds = 0;
-#define FC3D_BWD_CASE(KWV)                                                                                       \
-    if (Kw == KWV && (flds = wide_lds_plan<KWV>(Kh, L, true, &stage_all, &fcap)) != 0) {                          \
-        if (int e = allow_big_lds(code_pattern_bwd_wide_kernel<KWV>, flds)) return e;                            \
-        FC3D_LAUNCH("code_pattern_bwd", code_pattern_bwd_wide_kernel<KWV>, dim3(cdiv(W, WX), cdiv(H, WY), B),     \
-                    dim3(NT), flds, s, g_out, layer_u8, max_in, argmax_i32, (const float*)partial, nred, psf, H, \
-                    W, L, Kh, stage_all, fcap, (int)vec, g_pat0);                                                 \
-        return FC3D_OK;                                                                                          \
-    }
-        FC3D_FOR_WIDE_KW(FC3D_BWD_CASE)
-#undef FC3D_BWD_CASE
-    }
     auto k = vec ? code_pattern_bwd_kernel<true> : code_pattern_bwd_kernel<false>;
     FC3D_LAUNCH("code_pattern_bwd", k, dim3(cdiv(W, TX), cdiv(H, TY), B), dim3(NT), lds, s, g_out, layer_u8, max_in,
                 argmax_i32, (const float*)partial, nred, psf, H, W, L, Kh, Kw, conv_flag, cap, g_pat0);
