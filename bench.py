@@ -60,11 +60,11 @@ def parse():
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch override")
     ap.add_argument("--psf-k", type=int, default=None)
     ap.add_argument("--psf-kind", default="disc")
-    ap.add_argument("--launch", choices=("graph", "eager"), default="eager",
-                    help="eager: every launch issued from Python (about 125 us of host time per step, hidden "
-                         "behind ~245 us of kernels at the headline size); graph: the step is captured once into "
-                         "a HIP graph and replayed (same kernels, order and buffers; pays off when the kernels "
-                         "are shorter than the host's issue time, e.g. small batches)")
+    ap.add_argument("--launch", choices=("graph", "eager"), default="graph",
+                    help="graph: the step is captured once into a HIP graph and replayed (same kernels, order and "
+                         "buffers); eager: every launch issued from Python (about 125 us of host time per step; "
+                         "at the headline size that hides behind the kernels on a quiet host and is ~2%% faster "
+                         "than replay, but one run in three measured 15%% slower, so replay is the default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
