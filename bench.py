@@ -202,9 +202,13 @@ def main():
     timed_step, launch = step, "eager"
     if args.launch == "graph":
         from fc3d.graphs import GraphedImageFormation
-        gf = GraphedImageFormation(tens["pat"], tens["z_p"], tens["coord_p"], tens["coord_c"], tens["pose"],
-                                   tens["g"], tens["L"])
-        timed_step, launch = gf.replay, "hip_graph"
+        try:
+            gf = GraphedImageFormation(tens["pat"], tens["z_p"], tens["coord_p"], tens["coord_c"], tens["pose"],
+                                       tens["g"], tens["L"])
+            timed_step, launch = gf.replay, "hip_graph"
+        except Exception as e:   # capture refused (e.g. by another library's activity): measure eager instead
+            print(f"[bench] graph capture failed ({type(e).__name__}: {e}); using eager launches", file=sys.stderr)
+            torch.cuda.synchronize()
 
     def barrier():
         if dist is not None:

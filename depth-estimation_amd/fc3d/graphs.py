@@ -55,7 +55,9 @@ class GraphedImageFormation:
         torch.cuda.synchronize(dev)
         self.pattern.grad = None                   # so that .grad is allocated from the graph's pool
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # thread_local: calls made meanwhile by other threads of the process (e.g. the collective
+        # library's watchdog) do not invalidate the capture
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             outs = self._step()
         self.graph = g
         self.outputs = tuple(o.detach() for o in outs)
