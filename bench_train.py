@@ -48,8 +48,22 @@ def main():
     z_p, z_c, pose = d(sc["z_p"]), d(sc["z_c"]), d(sc["pose_p2c"])
     torch.manual_seed(1234)          # identical initial weights on every rank
     step = capture.TrainStep(dev)
-    for _ in range(args.warmup):
+    # The first steps can sit in the convolution library's kernel search for minutes without a
+    # word; a heartbeat on stderr tells a watching harness that the run is alive.
+    import threading
+    alive = threading.Event()
+
+    def heartbeat():
+        t_start = time.time()
+        while not alive.wait(45.0):
+            print(f"[bench_train] rank {rank}: warming up ({time.time() - t_start:.0f} s)", file=sys.stderr, flush=True)
+    hb = threading.Thread(target=heartbeat, daemon=True)
+    hb.start()
+    for i in range(args.warmup):
         step(z_p, z_c, pose)
+        torch.cuda.synchronize()
+        print(f"[bench_train] rank {rank}: warm-up step {i + 1}/{args.warmup} done", file=sys.stderr, flush=True)
+    alive.set()
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
