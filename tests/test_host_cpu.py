@@ -152,3 +152,33 @@ def test_data_parallel_helpers_gloo_two_ranks(tmp_path):
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("ok") == 2
+
+
+def test_capture_data_shards(tmp_path):
+    """The .npz reader: uint16 depth decoding (value/50000 + 0.3), split discovery, per-rank shares
+    that are disjoint, equally long and cover whole batches only, seeded shuffling."""
+    from fc3d import data, synth
+    sc = synth.make_scene(11, 16, 24, 5)
+    root = str(tmp_path) + os.sep
+    data.write_npz(root + "train_a.npz", sc["z_p"], sc["z_c"], sc["pose_p2c"], as_uint16=True)
+    data.write_npz(root + "test_a.npz", sc["z_p"], sc["z_c"], sc["pose_p2c"])
+    with pytest.raises(FileNotFoundError):
+        data.read_data(root, 2, "valid")
+    codes = np.load(root + "train_a.npz")["z_p"]
+    assert codes.dtype == np.uint16
+    assert np.array_equal(data.decode_depth(codes), codes.astype(np.float32) / np.float32(50000) + np.float32(0.3))
+    assert np.abs(data.decode_depth(codes) - sc["z_p"]).max() <= 0.5 / 50000 + 1e-7
+    seen = []
+    for rank in range(2):
+        sh = data.read_data(root, 2, "train", rank=rank, world=2, seed=3)
+        assert len(sh) == 2 and len(sh.index) == 4            # 11 samples -> 5 per rank -> 2 whole batches of 2
+        batches = list(sh)
+        assert len(batches) == 2 and tuple(batches[0]["z_p"].shape) == (2, 16, 24, 1)
+        assert batches[0]["z_p"].dtype == torch.float32 and tuple(batches[0]["pose_p2c"].shape) == (2, 4, 4)
+        again = [b["pose_p2c"] for b in data.read_data(root, 2, "train", rank=rank, world=2, seed=3)]
+        assert all(torch.equal(a, b["pose_p2c"]) for a, b in zip(again, batches))   # same seed, same order
+        seen.append(set(sh.index.tolist()))
+    assert not (seen[0] & seen[1]) and all(i % 2 == r for r in range(2) for i in seen[r])
+    seq = data.read_data(root, 3, "test")
+    first = next(iter(seq))
+    assert np.array_equal(first["z_p"].numpy(), sc["z_p"][:3]) and np.array_equal(first["pose_p2c"].numpy(), sc["pose_p2c"][:3])
