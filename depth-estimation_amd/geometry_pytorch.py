@@ -82,6 +82,8 @@ def points_in_camera_coords(z_map, pixel_to_ray_array, allBatch=False):
     (geometry_pytorch.py:44-65).  rays: numpy [H,W,3], or with allBatch a
     tensor [B,H,W,3]."""
     rays = pixel_to_ray_array
+    if z_map.shape[0] == 0:
+        return z_map.new_zeros((0, z_map.shape[1], z_map.shape[2], 4))
     if allBatch:
         return _ops.PointsFn.apply(z_map, None, None, rays.float())
     reg = _ray_registry.get(id(rays))
@@ -127,6 +129,8 @@ def _intrinsics_for(B: int, device: torch.device) -> torch.Tensor:
 def coord_transform(coord, transform):
     """[B,4,H,W] scene points x [B,4,4] -> pixel coordinates [B,H,W,2]
     (geometry_pytorch.py:68-90)."""
+    if coord.shape[0] == 0:
+        return coord.new_zeros((0, coord.shape[2], coord.shape[3], 2))
     return _ops.ProjectFn.apply(coord, transform)
 
 
@@ -134,6 +138,8 @@ def coord0TOgrid1(coord0, pose01):
     """Scene points of view 0 -> pixel coordinates in view 1 (geometry_pytorch.py:93-106)."""
     if pose01.requires_grad and torch.is_grad_enabled():
         raise NotImplementedError("coord0TOgrid1: gradient w.r.t. the pose is not implemented")
+    if coord0.shape[0] == 0:
+        return coord0.new_zeros((0, coord0.shape[2], coord0.shape[3], 2))
     K = _intrinsics_for(coord0.shape[0], coord0.device)
     T, _, _ = _ops.pose_transforms(pose01.detach(), K, want_fwd=True)
     return _ops.ProjectFn.apply(coord0, T)
@@ -142,6 +148,8 @@ def coord0TOgrid1(coord0, pose01):
 def bilinear_sampler(imgs, coords):
     """Bilinear sampling with the reference's clamp-then-weight rule
     (geometry_pytorch.py:109-177): imgs [B,Hs,Ws,C], coords [B,Ht,Wt,2] (x, y)."""
+    if imgs.shape[0] == 0:
+        return imgs.new_zeros((0, coords.shape[1], coords.shape[2], imgs.shape[3]))
     return _ops.BilinearFn.apply(imgs, coords)
 
 
@@ -154,6 +162,8 @@ def gen_visible_mask(grid, method='round'):
     else:
         # the reference falls through both branches and trips over an unset local
         raise UnboundLocalError("local variable 'grid_idx_1d' referenced before assignment")
+    if grid.shape[0] == 0:
+        return grid.new_zeros((0, grid.shape[1], grid.shape[2], 1))
     return _ops.visible_mask(grid, m)
 
 
@@ -166,6 +176,9 @@ def z2pointcloud(z):
 def warp_p2c(Ip, coord_p, coord_c, pose_p2c):
     """Projector image -> camera view with occluded pixels blacked out
     (geometry_pytorch.py:255-281).  Returns (Ic_masked, grid_p2c, grid_c2p)."""
+    if Ip.shape[0] == 0:                          # empty batch
+        e = coord_p.new_zeros((0, coord_p.shape[2], coord_p.shape[3], 2))
+        return Ip.clone(), e, e.clone()
     if torch.is_grad_enabled() and (coord_p.requires_grad or coord_c.requires_grad or pose_p2c.requires_grad):
         # rare differentiable-geometry case: compose the individual operators
         if pose_p2c.requires_grad:
@@ -190,5 +203,7 @@ def zp_cView_to_zc(zp_cView, pose_p2c, xy):
     (geometry_pytorch.py:284-308)."""
     if pose_p2c.requires_grad and torch.is_grad_enabled():
         raise NotImplementedError("zp_cView_to_zc: gradient w.r.t. the pose is not implemented")
+    if zp_cView.shape[0] == 0:
+        return zp_cView.clone()
     _, _, inv = _ops.pose_transforms(pose_p2c.detach(), None, want_a=True)
     return _ops.ZpToZcFn.apply(zp_cView, xy, inv)

@@ -116,6 +116,8 @@ def codePattern(pattern, zMap, device='cuda', is_conv_psf=True, n_layers=None):
     runs where the tensors are."""
     if pattern.dim() != 4 or zMap.dim() != 4:
         raise RuntimeError(f"codePattern expects [B,H,W,C] tensors, got {tuple(pattern.shape)}, {tuple(zMap.shape)}")
+    if pattern.shape[0] == 0:                     # empty batch: empty result, as the reference's tensor ops give
+        return pattern[..., 0:1].clone()
     L = int(pattern.shape[-1]) if n_layers is None else int(n_layers)
     if n_layers is not None and pattern.shape[-1] not in (1, L):
         raise RuntimeError(f"pattern has {pattern.shape[-1]} channels but n_layers={L}")

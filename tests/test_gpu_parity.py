@@ -433,6 +433,24 @@ def test_reproject_fused(mods, golden, monkeypatch):
     assert torch.equal(zf, zs) and torch.equal(If, Is)
 
 
+def test_empty_batch(mods):
+    """B = 0 gives empty results of the right shapes (the reference's tensor ops do the same)."""
+    G, O = mods["G"], mods["O"]
+    H, W = 8, 12
+    z = torch.zeros(0, H, W, 1, device="cuda")
+    assert tuple(O.codePattern(torch.zeros(0, H, W, 21, device="cuda"), z).shape) == (0, H, W, 1)
+    pts = G.points_in_camera_coords(z, G.pixel_to_ray_array(W, H))
+    assert tuple(pts.shape) == (0, H, W, 4)
+    coord = pts.permute(0, 3, 1, 2)
+    pose = torch.zeros(0, 4, 4, device="cuda")
+    Ic, g1, g2 = G.warp_p2c(z, coord, coord, pose)
+    assert tuple(Ic.shape) == (0, H, W, 1) and tuple(g1.shape) == (0, H, W, 2) and tuple(g2.shape) == (0, H, W, 2)
+    assert tuple(G.coord0TOgrid1(coord, pose).shape) == (0, H, W, 2)
+    assert tuple(G.bilinear_sampler(torch.zeros(0, H, W, 3, device="cuda"), g1).shape) == (0, H, W, 3)
+    assert tuple(G.gen_visible_mask(g1, "all").shape) == (0, H, W, 1)
+    assert tuple(G.zp_cView_to_zc(z, pose, g1).shape) == (0, H, W, 1)
+
+
 def test_errors_are_loud(mods):
     G, O = mods["G"], mods["O"]
     with pytest.raises(RuntimeError):
