@@ -727,81 +727,101 @@ void code_pattern_fwd_roll_kernel(
 // Layer-sweep kernels for large odd square PSFs (9x9 ... 33x33).
 //
 // At these sizes the work is K*K multiply-adds per pixel and direction, so the aim is to keep the
-// vector ALUs on multiply-adds and nothing else.  One wavefront (a 64-thread workgroup) owns 64
-// columns x R rows of output and stages the (R+K-1) x (64+K-1) input tile in LDS.  It then sweeps
-// over the depth layers present, one at a time, so that within a sweep the PSF is the same for
-// every lane: a PSF row is K scalar registers (s_load from the PSF stack), never a per-lane
-// operand.  For one input row the lane reads its K neighbours from LDS once and reuses them for
-// every output row that row feeds (K multiply-adds each), about R*K/(R+K-1) multiply-adds per
-// LDS read.  Rows without a pixel of the current layer are skipped, so the cost per pixel is K*K
-// times the number of layers met in its row segment (about 1.7 at 64 columns), not times L.
+// vector ALUs on multiply-adds and nothing else.  One wavefront (a 64-thread workgroup) owns a
+// 16 x 16 output tile -- 16 columns x 4 row groups of lanes, R = 4 rows per lane -- and stages the
+// (16+K-1)^2 input tile in LDS.  It then sweeps over the depth layers present, one at a time, so
+// that within a sweep the PSF is the same for every lane: a PSF row is K scalar registers (s_load
+// from the PSF stack, constant offsets), never a per-lane operand.  For one input row the lane
+// reads its K neighbours from LDS once and reuses them for every output row that row feeds (K
+// multiply-adds each), about R*K/(R+K-1) multiply-adds per LDS read.  The cost per pixel is K*K
+// times the number of layers met in the tile, not times L; the square tile keeps that number
+// (and the halo) small.  The LDS row stride is chosen so that the four row groups fall into
+// different banks.
 //
 // Forward: a sweep of layer l computes the blur with PSF l for every lane and keeps it where
 // the output pixel's layer is l (summation order dy, then dx ascending, as in the other forward
 // kernels).  Backward: a sweep of layer l blurs the gradient image masked to the *source* pixels
-// of layer l (flipped PSF) and the sweeps add up; the masked row is built in a one-row LDS buffer.
+// of layer l (flipped PSF) and the sweeps add up; the masked tile is a second LDS copy rebuilt
+// once per sweep.
 // ---------------------------------------------------------------------------------------
-template <int K>
+#ifndef FC3D_SWEEP_COLS
+#define FC3D_SWEEP_COLS 16
+#endif
+#ifndef FC3D_SWEEP_ROWS
+#define FC3D_SWEEP_ROWS 4
+#endif
+constexpr int kSweepCols = FC3D_SWEEP_COLS;       // output columns per wavefront (64 / kSweepCols row groups)
+constexpr int kSweepRows = FC3D_SWEEP_ROWS;       // output rows per lane
+constexpr int kSweepTileRows = (64 / kSweepCols) * kSweepRows;
+#define FC3D_FOR_SWEEP_K(X) X(9) X(11) X(13) X(15) X(17) X(19) X(21) X(23) X(25) X(27) X(29) X(31) X(33)
+
+template <int K, int R, int CW>
 struct Sweep {
     static constexpr int PAD = (K - 1) / 2;
-    static constexpr int LW = 64 + K - 1;         // staged columns
-    static constexpr int LWB = (LW + 3) & ~3;     // bytes per row of the staged layer tile
+    static constexpr int NG = 64 / CW;            // row groups of lanes
+    static constexpr int TR = NG * R;             // output rows per wavefront
+    static constexpr int NR = TR + K - 1;         // staged rows
+    static constexpr int LW0 = CW + K - 1;        // staged columns
+    // row stride: R * LW = 16 (mod 64) puts the NG groups' 16-lane reads into different banks
+    static constexpr int LW = NG == 1 ? LW0 : LW0 + ((4 - LW0 % 16) + 16) % 16;
+    static constexpr int LWB = (LW0 + 3) & ~3;    // bytes per row of the staged layer tile
+    static_assert(NG == 1 || R == 4, "the bank-spreading stride assumes four rows per lane");
 };
 
-// Stages rows [0, NR) x LW columns of a plane into LDS; out-of-image cells get `fill`.  Loads are
-// unconditional from clamped addresses, eight rows per batch.
-template <int K, int NR, typename T, typename F>
+// Stages NR x LW0 cells of a plane (top-left cell at image position (x_first, y_first)) through
+// put(row, column, value, inside_image).  Loads are unconditional from clamped addresses, eight
+// per lane in flight.
+template <int NR, int LW0, typename T, typename F>
 __device__ __forceinline__ void sweep_stage(const T* __restrict__ plane, unsigned row_stride, unsigned col_stride,
                                             int H, int W, int x_first, int y_first, int lane, F put) {
-    constexpr int LW = Sweep<K>::LW;
-    const int gx0 = x_first + lane, gx1 = x_first + 64 + lane;
-    const bool ok0 = gx0 >= 0 && gx0 < W, ok1 = (lane < K - 1) && gx1 >= 0 && gx1 < W;
-    const unsigned c0 = (unsigned)min(max(gx0, 0), W - 1) * col_stride, c1 = (unsigned)min(max(gx1, 0), W - 1) * col_stride;
-    for (int r0 = 0; r0 < NR; r0 += 8) {
-        T a[8], b2[8];
+    constexpr int N = NR * LW0;
+    for (int i0 = 0; i0 < N; i0 += 64 * 8) {
+        T v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const unsigned ro = (unsigned)min(max(y_first + r0 + u, 0), H - 1) * row_stride;
-            a[u] = ld_at(plane, ro + c0);
-            b2[u] = ld_at(plane, ro + c1);
+            const int i = min(i0 + u * 64 + lane, N - 1);
+            const int r = i / LW0, c = i - r * LW0;
+            v[u] = ld_at(plane, (unsigned)min(max(y_first + r, 0), H - 1) * row_stride +
+                                    (unsigned)min(max(x_first + c, 0), W - 1) * col_stride);
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int r = r0 + u, gy = y_first + r;
-            if (r < NR) {
-                const bool rowok = gy >= 0 && gy < H;
-                put(r, lane, a[u], rowok && ok0);
-                if (lane < K - 1) put(r, 64 + lane, b2[u], rowok && ok1);
+            const int i = i0 + u * 64 + lane;
+            if (i < N) {
+                const int r = i / LW0, c = i - r * LW0;
+                const int gy = y_first + r, gx = x_first + c;
+                put(r, c, v[u], gy >= 0 && gy < H && gx >= 0 && gx < W);
             }
         }
     }
-    (void)LW;
 }
 
-template <int K, int R>
+template <int K, int R, int CW>
 __global__ __launch_bounds__(64) void code_pattern_fwd_sweep_kernel(
     const float* __restrict__ pat0, long sb, long sh, long sw, const float* __restrict__ z,
     const float* __restrict__ psf, int H, int W, fc3d_layer_grid lg, float* __restrict__ raw,
     uint8_t* __restrict__ layer_u8, unsigned long long* __restrict__ tilekey) {
-    constexpr int PAD = Sweep<K>::PAD, LW = Sweep<K>::LW, NR = R + K - 1;
+    using S = Sweep<K, R, CW>;
+    constexpr int PAD = S::PAD, LW = S::LW, NRG = R + K - 1;       // NRG: input rows one row group reads
     extern __shared__ float smem[];               // [NR][LW]
-    const int lane = threadIdx.x;
-    const int b = blockIdx.z, x0 = blockIdx.x * 64, y0 = blockIdx.y * R;
+    const int lane = threadIdx.x, col = lane % CW, grp = lane / CW;
+    const int b = blockIdx.z, x0 = blockIdx.x * CW, y0 = blockIdx.y * S::TR;
     const long img = (long)b * H * W;
-    const int x = x0 + lane;
+    const int x = x0 + col, yg = y0 + grp * R;
 
-    sweep_stage<K, NR>(pat0 + (long)b * sb, (unsigned)sh, (unsigned)sw, H, W, x0 - PAD, y0 - PAD, lane,
-                       [&](int r, int c, float v, bool ok) { smem[r * LW + c] = ok ? v : 0.0f; });
+    sweep_stage<S::NR, S::LW0>(pat0 + (long)b * sb, (unsigned)sh, (unsigned)sw, H, W, x0 - PAD, y0 - PAD, lane,
+                               [&](int r, int c, float v, bool ok) { smem[r * LW + c] = ok ? v : 0.0f; });
     int lay[R];
 #pragma unroll
     for (int o = 0; o < R; ++o) {
-        const int y = y0 + o;
+        const int y = yg + o;
         const bool inb = y < H && x < W;
         const float zv = ld_at(z + img, (unsigned)(min(y, H - 1) * W + min(x, W - 1)));
         lay[o] = inb ? layer_of(zv, lg) : -1;
     }
     __syncthreads();
 
+    const float* mine = smem + grp * R * LW + col;               // this lane's window: rows grp*R .., columns col ..
     float res[R];
 #pragma unroll
     for (int o = 0; o < R; ++o) res[o] = 0.0f;
@@ -815,7 +835,7 @@ __global__ __launch_bounds__(64) void code_pattern_fwd_sweep_kernel(
         if (cand == 0x7fffffff) break;
         last = cand;
         const int l = __builtin_amdgcn_readfirstlane(cand);     // the layer of this sweep, in a scalar register
-        unsigned rows = 0;                                       // output rows with a pixel of layer l
+        unsigned rows = 0;                                       // row slots in which some lane has a pixel of layer l
 #pragma unroll
         for (int o = 0; o < R; ++o)
             if (__ballot(lay[o] == l) != 0ull) rows |= 1u << o;
@@ -833,7 +853,7 @@ __global__ __launch_bounds__(64) void code_pattern_fwd_sweep_kernel(
             }
             float in[K];
 #pragma unroll
-            for (int dx = 0; dx < K; ++dx) in[dx] = smem[r * LW + lane + dx];
+            for (int dx = 0; dx < K; ++dx) in[dx] = mine[r * LW + dx];
             // PSF row dy = r - o of layer l sits (R-1-o)*K floats after wbase: constant offsets for the scalar loads
             const float* wbase = psf + ((long)l * K + (r - (R - 1))) * K;
 #pragma unroll
@@ -848,7 +868,7 @@ __global__ __launch_bounds__(64) void code_pattern_fwd_sweep_kernel(
         };
         for (int r = 0; r < R - 1; ++r) row_step(r, std::false_type{});
         for (int r = R - 1; r < K; ++r) row_step(r, std::true_type{});
-        for (int r = K; r < NR; ++r) row_step(r, std::false_type{});
+        for (int r = K; r < NRG; ++r) row_step(r, std::false_type{});
 #pragma unroll
         for (int o = 0; o < R; ++o)
             if (lay[o] == l) res[o] = acc[o];
@@ -857,7 +877,7 @@ __global__ __launch_bounds__(64) void code_pattern_fwd_sweep_kernel(
     unsigned long long key = 0;
 #pragma unroll
     for (int o = 0; o < R; ++o) {
-        const int y = y0 + o;
+        const int y = yg + o;
         const float a = res[o] * (lay[o] >= 0 ? 1.0f : 0.0f);    // a multiply: a non-finite blur still poisons the pixel
         if (y < H && x < W) {
             const uint32_t pos = 0xffffffffu - (uint32_t)(x * H + y);   // first w, then first h
@@ -872,31 +892,32 @@ __global__ __launch_bounds__(64) void code_pattern_fwd_sweep_kernel(
     if (lane == 0) tilekey[((long)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = key;
 }
 
-// LDS bytes of the backward sweep kernel: gradient tile, one masked row, layer tile, per-layer and
-// per-row-per-layer presence flags.
-template <int K, int R>
+// LDS bytes of the backward sweep kernel: gradient tile, its copy masked to the current layer,
+// layer tile, per-layer and per-row-per-layer presence flags.
+template <int K, int R, int CW>
 static size_t sweep_bwd_lds(int L) {
-    constexpr int NR = R + K - 1;
-    return (size_t)NR * Sweep<K>::LW * 4 + (size_t)Sweep<K>::LW * 4 + (size_t)NR * Sweep<K>::LWB + 256 + (size_t)NR * L + 4;
+    using S = Sweep<K, R, CW>;
+    return (size_t)S::NR * S::LW * 4 * 2 + (size_t)S::NR * S::LWB + 256 + (size_t)S::NR * L + 4;
 }
 
-template <int K, int R>
+template <int K, int R, int CW>
 __global__ __launch_bounds__(64) void code_pattern_bwd_sweep_kernel(
     const float* __restrict__ g, const float* __restrict__ out, const uint8_t* __restrict__ layer_u8,
     const float* __restrict__ max_in, const float* __restrict__ psf, int H, int W, int L,
     float* __restrict__ partial, float* __restrict__ g_pat0) {
-    constexpr int PAD = Sweep<K>::PAD, LW = Sweep<K>::LW, LWB = Sweep<K>::LWB, NR = R + K - 1;
+    using S = Sweep<K, R, CW>;
+    constexpr int PAD = S::PAD, LW = S::LW, LW0 = S::LW0, LWB = S::LWB, NR = S::NR, NG = S::NG, NRG = R + K - 1;
     constexpr int HB = K - 1 - PAD;               // halo rows / columns before the tile
     extern __shared__ float smem[];
     float* gt = smem;                                              // [NR][LW] gradient / (max + eps), 0 where masked
-    float* mrow = smem + NR * LW;                                  // [LW] current row masked to the current layer
-    uint8_t* lt = reinterpret_cast<uint8_t*>(mrow + LW);           // [NR][LWB] layer of every staged pixel (255: none)
+    float* mt = smem + NR * LW;                                    // [NR][LW] the tile masked to the current layer
+    uint8_t* lt = reinterpret_cast<uint8_t*>(mt + NR * LW);        // [NR][LWB] layer of every staged pixel (255: none)
     uint8_t* present = lt + NR * LWB;                              // [256] layer occurs in the tile
     uint8_t* rowpres = present + 256;                              // [NR][L] layer occurs in staged row r
-    const int lane = threadIdx.x;
-    const int b = blockIdx.z, x0 = blockIdx.x * 64, y0 = blockIdx.y * R;
+    const int lane = threadIdx.x, col = lane % CW, grp = lane / CW;
+    const int b = blockIdx.z, x0 = blockIdx.x * CW, y0 = blockIdx.y * S::TR;
     const long img = (long)b * H * W;
-    const int x = x0 + lane;
+    const int x = x0 + col, yg = y0 + grp * R;
     const float rden = 1.0f / (max_in[b] + 1e-10f);
 
     for (int i = lane; i < 64 + NR * L / 4 + 1; i += 64) {        // clear the flags, 4 bytes per lane and step
@@ -904,22 +925,22 @@ __global__ __launch_bounds__(64) void code_pattern_bwd_sweep_kernel(
         else if ((i - 64) * 4 < NR * L) reinterpret_cast<uint32_t*>(rowpres)[i - 64] = 0u;
     }
     __syncthreads();
-    sweep_stage<K, NR>(layer_u8 + img, (unsigned)W, 1u, H, W, x0 - HB, y0 - HB, lane,
-                       [&](int r, int c, uint8_t v, bool ok) {
-                           const uint8_t l = ok ? v : (uint8_t)255;
-                           lt[r * LWB + c] = l;
-                           if (l != 255) {
-                               present[l] = 1;
-                               rowpres[r * L + l] = 1;
-                           }
-                       });
-    sweep_stage<K, NR>(g + img, (unsigned)W, 1u, H, W, x0 - HB, y0 - HB, lane,
-                       [&](int r, int c, float v, bool ok) { gt[r * LW + c] = ok ? v * rden : 0.0f; });
+    sweep_stage<NR, LW0>(layer_u8 + img, (unsigned)W, 1u, H, W, x0 - HB, y0 - HB, lane,
+                         [&](int r, int c, uint8_t v, bool ok) {
+                             const uint8_t l = ok ? v : (uint8_t)255;
+                             lt[r * LWB + c] = l;
+                             if (l != 255) {
+                                 present[l] = 1;
+                                 rowpres[r * L + l] = 1;
+                             }
+                         });
+    sweep_stage<NR, LW0>(g + img, (unsigned)W, 1u, H, W, x0 - HB, y0 - HB, lane,
+                         [&](int r, int c, float v, bool ok) { gt[r * LW + c] = ok ? v * rden : 0.0f; });
     // sum of g*out over the pixels this wavefront owns (for the gradient through the per-image maximum)
     float sgo = 0.0f;
 #pragma unroll
     for (int o = 0; o < R; ++o) {
-        const int y = y0 + o;
+        const int y = yg + o;
         const unsigned q = (unsigned)(min(y, H - 1) * W + min(x, W - 1));
         const float gv = ld_at(g + img, q), ov = ld_at(out + img, q);
         sgo = fmaf((y < H && x < W) ? gv : 0.0f, ov, sgo);
@@ -931,20 +952,27 @@ __global__ __launch_bounds__(64) void code_pattern_bwd_sweep_kernel(
     float acc[R];
 #pragma unroll
     for (int o = 0; o < R; ++o) acc[o] = 0.0f;
+    const float* mine = mt + grp * R * LW + col;                  // this lane's window: rows grp*R .., columns col ..
     for (int l = 0; l < L; ++l) {
         if (__builtin_amdgcn_readfirstlane((int)present[l]) == 0) continue;
-        // staged row r, column lane+e is source (y0-HB+r, x-HB+e); it reaches output row o through PSF
-        // row K-1-(r-o) and PSF column K-1-e.  Rows R-1 .. K-1 feed all R output rows (straight-line
-        // code, see the forward kernel); the first and last R-1 rows take the branchy form.
+        __syncthreads();                          // the previous sweep's reads of mt are done
+        for (int i = lane; i < NR * LW0; i += 64) {
+            const int r = i / LW0, c = i - r * LW0;
+            mt[r * LW + c] = (lt[r * LWB + c] == (uint8_t)l) ? gt[r * LW + c] : 0.0f;
+        }
+        __syncthreads();
+        // Row r of a group's window, column col+e is source (yg-HB+r, x-HB+e); it reaches output row o
+        // through PSF row K-1-(r-o) and PSF column K-1-e.  Rows R-1 .. K-1 feed all R output rows
+        // (straight-line code, see the forward kernel); the first and last R-1 rows take the branchy form.
         auto row_step = [&](int r, auto full) {
             constexpr bool FULL = decltype(full)::value;
-            if (__builtin_amdgcn_readfirstlane((int)rowpres[r * L + l]) == 0) return;
-            __syncthreads();                      // the previous row's reads of mrow are done
-            for (int c = lane; c < LW; c += 64) mrow[c] = (lt[r * LWB + c] == (uint8_t)l) ? gt[r * LW + c] : 0.0f;
-            __syncthreads();
+            int any = 0;
+#pragma unroll
+            for (int gq = 0; gq < NG; ++gq) any |= (int)rowpres[(gq * R + r) * L + l];
+            if (__builtin_amdgcn_readfirstlane(any) == 0) return;
             float in[K];
 #pragma unroll
-            for (int e = 0; e < K; ++e) in[e] = mrow[lane + e];
+            for (int e = 0; e < K; ++e) in[e] = mine[r * LW + e];
             // PSF row K-1-(r-o) of layer l sits o*K floats after wbase: constant offsets for the scalar loads
             const float* wbase = psf + ((long)l * K + (K - 1 - r)) * K;
 #pragma unroll
@@ -959,20 +987,14 @@ __global__ __launch_bounds__(64) void code_pattern_bwd_sweep_kernel(
         };
         for (int r = 0; r < R - 1; ++r) row_step(r, std::false_type{});
         for (int r = R - 1; r < K; ++r) row_step(r, std::true_type{});
-        for (int r = K; r < NR; ++r) row_step(r, std::false_type{});
+        for (int r = K; r < NRG; ++r) row_step(r, std::false_type{});
     }
 #pragma unroll
     for (int o = 0; o < R; ++o) {
-        const int y = y0 + o;
+        const int y = yg + o;
         if (y < H && x < W) st_at(g_pat0 + img, (unsigned)(y * W + x), acc[o]);
     }
 }
-
-#ifndef FC3D_SWEEP_ROWS
-#define FC3D_SWEEP_ROWS 4
-#endif
-constexpr int kSweepRows = FC3D_SWEEP_ROWS;                     // output rows per wavefront of the layer-sweep kernels
-#define FC3D_FOR_SWEEP_K(X) X(9) X(11) X(13) X(15) X(17) X(19) X(21) X(23) X(25) X(27) X(29) X(31) X(33)
 
 #ifndef FC3D_ROLL_ROWS
 #define FC3D_ROLL_ROWS 8
@@ -1011,7 +1033,7 @@ extern "C" size_t fc3d_code_pattern_fwd_workspace(int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0) return 0;
     const long a = (long)cdiv(W, TX) * cdiv(H, TY);
     const long r = (long)cdiv(cdiv(W, Roll<7>::SW), NT / 64) * (NT / 64) * cdiv(H, kRollRows);
-    const long sw = (long)cdiv(W, 64) * cdiv(H, kSweepRows);
+    const long sw = (long)cdiv(W, kSweepCols) * cdiv(H, kSweepTileRows);
     long m = a > r ? a : r;
     m = sw > m ? sw : m;
     return (size_t)B * m * sizeof(unsigned long long);
@@ -1021,7 +1043,7 @@ extern "C" size_t fc3d_code_pattern_bwd_workspace(int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0) return 0;
     const long a = cdiv((long)H * W, RED_PX);
     const long r = (long)cdiv(cdiv(W, Roll<7>::SW), NT / 64) * (NT / 64) * cdiv(H, kRollRowsBwd);
-    const long sw = (long)cdiv(W, 64) * cdiv(H, kSweepRows);
+    const long sw = (long)cdiv(W, kSweepCols) * cdiv(H, kSweepTileRows);
     long m = a > r ? a : r;
     m = sw > m ? sw : m;
     return (size_t)B * m * sizeof(float);
@@ -1066,12 +1088,13 @@ extern "C" int fc3d_code_pattern_fwd(void* stream, const float* pat0, int64_t pa
 #undef FC3D_FWD_ROLL_CASE
 #define FC3D_FWD_SWEEP_CASE(KV)                                                                                  \
     if (Kw == KV) {                                                                                              \
-        const size_t slds = (size_t)(kSweepRows + KV - 1) * Sweep<KV>::LW * sizeof(float);                       \
-        const dim3 gsw(cdiv(W, 64), cdiv(H, kSweepRows), B);                                                     \
+        using SW = Sweep<KV, kSweepRows, kSweepCols>;                                                            \
+        const size_t slds = (size_t)SW::NR * SW::LW * sizeof(float);                                             \
+        const dim3 gsw(cdiv(W, kSweepCols), cdiv(H, kSweepTileRows), B);                                         \
         *keys_per_image = (int)(gsw.x * gsw.y);                                                                  \
-        FC3D_LAUNCH("code_pattern_fwd", (code_pattern_fwd_sweep_kernel<KV, kSweepRows>), gsw, dim3(64), slds, s, \
-                    pat0, (long)pat_sb, (long)pat_sh, (long)pat_sw, z, psf, H, W, grid, raw_out, layer_u8,       \
-                    (unsigned long long*)tilekey_u64);                                                           \
+        FC3D_LAUNCH("code_pattern_fwd", (code_pattern_fwd_sweep_kernel<KV, kSweepRows, kSweepCols>), gsw,        \
+                    dim3(64), slds, s, pat0, (long)pat_sb, (long)pat_sh, (long)pat_sw, z, psf, H, W, grid,       \
+                    raw_out, layer_u8, (unsigned long long*)tilekey_u64);                                        \
         return FC3D_OK;                                                                                          \
     }
         FC3D_FOR_SWEEP_K(FC3D_FWD_SWEEP_CASE)
@@ -1135,10 +1158,10 @@ extern "C" int fc3d_code_pattern_bwd(void* stream, const float* g_out, const flo
 #undef FC3D_BWD_ROLL_CASE
 #define FC3D_BWD_SWEEP_CASE(KV)                                                                                  \
     if (Kw == KV) {                                                                                              \
-        const size_t slds = sweep_bwd_lds<KV, kSweepRows>(L);                                                    \
-        const dim3 gsw(cdiv(W, 64), cdiv(H, kSweepRows), B);                                                     \
-        FC3D_LAUNCH("code_pattern_bwd", (code_pattern_bwd_sweep_kernel<KV, kSweepRows>), gsw, dim3(64), slds, s, \
-                    g_out, out, layer_u8, max_in, psf, H, W, L, partial, g_pat0);                                \
+        const size_t slds = sweep_bwd_lds<KV, kSweepRows, kSweepCols>(L);                                        \
+        const dim3 gsw(cdiv(W, kSweepCols), cdiv(H, kSweepTileRows), B);                                         \
+        FC3D_LAUNCH("code_pattern_bwd", (code_pattern_bwd_sweep_kernel<KV, kSweepRows, kSweepCols>), gsw,        \
+                    dim3(64), slds, s, g_out, out, layer_u8, max_in, psf, H, W, L, partial, g_pat0);             \
         FC3D_LAUNCH("code_pattern_bwd_max", code_pattern_bwd_max_kernel, dim3(B), dim3(NT), 0, s,                \
                     (const float*)partial, (int)(gsw.x * gsw.y), max_in, argmax_i32, layer_u8, psf, H, W, KV,    \
                     g_pat0);                                                                                     \
