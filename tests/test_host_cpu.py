@@ -182,3 +182,12 @@ def test_capture_data_shards(tmp_path):
     seq = data.read_data(root, 3, "test")
     first = next(iter(seq))
     assert np.array_equal(first["z_p"].numpy(), sc["z_p"][:3]) and np.array_equal(first["pose_p2c"].numpy(), sc["pose_p2c"][:3])
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    """No fallback: without the shared library the binding refuses to load."""
+    from fc3d import _native
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "LIB_PATH", os.path.join(ROOT, "does", "not", "exist", "libfc3d_hip.so"))
+    with pytest.raises(ImportError, match="no fallback"):
+        _native.load()
