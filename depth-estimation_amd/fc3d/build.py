@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libfc3d_hip.so")
-SOURCES = ["optics.hip", "geometry.hip", "profile.hip"]
+SOURCES = ["optics.hip", "geometry.hip", "capture.hip", "profile.hip"]
 
 # -ffp-contract=off                         index/mask decisions need the reference's separately rounded ops
 # -fhip-fp32-correctly-rounded-divide-sqrt  IEEE fp32 division (torch's CPU kernels divide exactly)

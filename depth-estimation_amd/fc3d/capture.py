@@ -89,29 +89,48 @@ def centre_crop(t, N):
     return t[:, h0:h0 + N, w0:w0 + N, :]
 
 
-def forward_model(z_p, z_c, pose_p2c, n_layers=21, is_conv_psf=True, crop=None, noise=None, pattern=None):
+def _draw_noise(B, H, W, dev):
+    return dict(offset=torch.rand(B, 1, 1, 1, device=dev), gauss=torch.randn(B, H, W, 1, device=dev),
+                scale=torch.rand(B, 1, 1, 1, device=dev))
+
+
+def forward_model(z_p, z_c, pose_p2c, n_layers=21, is_conv_psf=True, crop=None, noise=None, pattern=None, fused=True):
     """Simulated capture; train_pytorch.py:79-162.  noise: optional dict(offset [B,1,1,1] in
-    [0,1), gauss [B,H,W,1] ~ N(0,1), scale [B,1,1,1] in [0,1)); drawn on the device if absent."""
+    [0,1), gauss [B,H,W,1] ~ N(0,1), scale [B,1,1,1] in [0,1)); drawn on the device if absent.
+    fused=True (used when nothing asks for a gradient, as in the reference's loop) runs the
+    capture kernels: shading, codePattern, warp straight from the depth maps, sensor model;
+    fused=False composes the drop-in operators with tensor arithmetic as the reference does."""
     B, H, W, _ = z_p.shape
     dev = z_p.device
+    Ip = dot_pattern(H, W, dev) if pattern is None else pattern
+    if noise is None:
+        noise = _draw_noise(B, H, W, dev)
+    c = lambda t: centre_crop(t, crop)  # noqa: E731
+    xy = _rays_xy(H, W, dev).unsqueeze(0).expand(B, -1, -1, -1)
+    if fused and B > 0 and not (torch.is_grad_enabled() and any(t.requires_grad for t in (z_p, z_c, pose_p2c, Ip))):
+        from . import ops
+        rx, ry = G._separable_rays(W, H, dev)
+        Ip_coded = O.codePattern(ops.reflectance(Ip, z_p), z_p, is_conv_psf=is_conv_psf, n_layers=n_layers)
+        # the launch that forms the two transforms also clears the visibility mask for the splat
+        mask = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+        T_p2c, T_c2p, _ = ops.pose_transforms(pose_p2c.detach(), G._intrinsics_for(B, dev), want_fwd=True, want_inv=True,
+                                              clear=mask)
+        Ic, xyz_cView, mask = ops.capture_warp(Ip_coded, z_p, z_c, rx, ry, T_p2c, T_c2p, zero_mask=mask)
+        Ic_scaled, Ic_mask = ops.capture_post(Ic, noise["offset"], noise["gauss"], noise["scale"], mask)
+        return (c(Ic_scaled), c(Ic_mask), c(xyz_cView), c(xy), c(z_c), c(z_p), pose_p2c, z_p, c(Ic), Ip_coded,
+                Ic_scaled)
     rays = G.pixel_to_ray_array(W, H)
     coord_p = G.points_in_camera_coords(z_p, rays).permute(0, 3, 1, 2)
     coord_c = G.points_in_camera_coords(z_c, rays).permute(0, 3, 1, 2)
-    Ip = dot_pattern(H, W, dev) if pattern is None else pattern
     Ip_ref = with_reflectance(Ip, z_p)
     Ip_coded = O.codePattern(Ip_ref, z_p, is_conv_psf=is_conv_psf, n_layers=n_layers)
     Ic, grid_p2c, grid_c2p = G.warp_p2c(Ip_coded, coord_p, coord_c, pose_p2c)
-    if noise is None:
-        noise = dict(offset=torch.rand(B, 1, 1, 1, device=dev), gauss=torch.randn(B, H, W, 1, device=dev),
-                     scale=torch.rand(B, 1, 1, 1, device=dev))
     Ic_exp = Ic + noise["offset"] * 0.05 + noise["gauss"] * 0.005
     Ic_max = Ic_exp.amax(dim=(1, 2), keepdim=True)
     Ic_scaled = torch.clamp(Ic_exp / Ic_max * (noise["scale"] * 0.3 + 0.7), 0.0, 1.0)
     vis = G.gen_visible_mask(grid_p2c, 'all')
-    xy = _rays_xy(H, W, dev).unsqueeze(0).expand(B, -1, -1, -1)
     xyz_cView = G.bilinear_sampler(torch.cat([xy, z_p], dim=-1), grid_c2p) * vis
     Ic_mask = (Ic_scaled > 0.05).float() * vis
-    c = lambda t: centre_crop(t, crop)  # noqa: E731
     return (c(Ic_scaled), c(Ic_mask), c(xyz_cView), c(xy), c(z_c), c(z_p), pose_p2c, z_p, c(Ic), Ip_coded, Ic_scaled)
 
 

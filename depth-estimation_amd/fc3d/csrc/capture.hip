@@ -1,0 +1,326 @@
+// The capture simulator around the image-formation path (forward only; the reference runs it
+// without gradients): surface-slope shading of the pattern (utils_pytorch.py:251-280), the warp of
+// the coded pattern taken straight from the two depth maps (train_pytorch.py:86-87, 97, 107-116)
+// and the sensor model (train_pytorch.py:100-104, 118).
+//
+// The composed operators move the scene points ([B,H,W,4] twice), both sampling grids and an
+// [B,H,W,3] concatenation through HBM only to consume them once.  Here a scene point is formed
+// in registers from its depth and the separable ray table, the grids are written only if asked
+// for, and the camera-view scene coordinates are blended from the taps the pattern already uses:
+// 4 B/px in and marks out for the forward splat, 9 B/px in and 16 B/px out (plus gathers that hit
+// the caches) for the inverse warp.  Every value that decides an index, a mask bit or a threshold
+// is computed with the operations and the order of the composed operators, so the outputs are
+// bit-identical to theirs.
+#include "geom_dev.h"
+
+namespace fc3d {
+
+// I * (0.8 cos(atan(|grad z| / 100 um)) + 0.2) with forward differences that are zero on the last
+// row / column.  cos(atan(t)) is evaluated as 1/sqrt(1 + t^2): the same function without the two
+// transcendental roundings (result within 1e-6 relative of the composed form).
+__global__ __launch_bounds__(NT) void reflectance_kernel(const float* __restrict__ I, long i_sb,
+                                                         const float* __restrict__ z, int H, int W,
+                                                         float* __restrict__ out) {
+    const int b = blockIdx.y;
+    const unsigned HW = (unsigned)H * (unsigned)W;
+    const unsigned p = blockIdx.x * NT + threadIdx.x;
+    if (p >= HW) return;
+    const unsigned y = p / (unsigned)W, x = p - y * (unsigned)W;
+    const float* zb = z + (long)b * HW;
+    const float z0 = zb[p];
+    const float dx = (x + 1 < (unsigned)W) ? __fsub_rn(zb[p + 1], z0) : 0.0f;
+    const float dy = (y + 1 < (unsigned)H) ? __fsub_rn(zb[p + W], z0) : 0.0f;
+    const float t = sqrtf(__fadd_rn(__fmul_rn(dy, dy), __fmul_rn(dx, dx))) / 100e-6f;
+    const float c = 1.0f / sqrtf(__fadd_rn(1.0f, __fmul_rn(t, t)));
+    out[(long)b * HW + p] = __fmul_rn(I[(long)b * i_sb + p], __fadd_rn(__fmul_rn(c, 0.8f), 0.2f));
+}
+
+// Scene point of pixel p at depth z: (z * ray_x[x], z * ray_y[y], z * 1, 1), the products rounded
+// separately like the stored point cloud of the composed path.
+__device__ __forceinline__ void point_of(float z, const float* __restrict__ ray_x, const float* __restrict__ ray_y,
+                                         unsigned p, unsigned W, float c[4]) {
+    const unsigned y = p / W, x = p - y * W;
+    c[0] = __fmul_rn(z, ray_x[x]);
+    c[1] = __fmul_rn(z, ray_y[y]);
+    c[2] = __fmul_rn(z, 1.0f);
+    c[3] = 1.0f;
+}
+
+// Forward warp: projector pixel -> camera pixel, 'all' visibility splat; the grid is optional.
+template <bool FMA>
+__global__ __launch_bounds__(NT) void capture_project_kernel(const float* __restrict__ z_p,
+                                                             const float* __restrict__ ray_x,
+                                                             const float* __restrict__ ray_y,
+                                                             const float* __restrict__ Tm, int H, int W,
+                                                             float* __restrict__ grid, uint8_t* __restrict__ mask_u8) {
+    const int b = blockIdx.y;
+    const long HW = (long)H * W;
+    const long p0 = lane_first_pixel();
+    const float* T = Tm + (long)b * 16;
+    const float* zb = z_p + (long)b * HW;
+    float z[PPL];
+#pragma unroll
+    for (int i = 0; i < PPL; ++i) {
+        const long p = p0 + 64 * i;
+        if (p < HW) z[i] = zb[p];
+    }
+    float2* go = grid ? reinterpret_cast<float2*>(grid) + (long)b * HW : nullptr;
+    uint8_t* m = mask_u8 + (long)b * HW;
+#pragma unroll
+    for (int i = 0; i < PPL; ++i) {
+        const long p = p0 + 64 * i;
+        if (p < HW) {
+            float c[4], gx, gy;
+            point_of(z[i], ray_x, ray_y, (unsigned)p, (unsigned)W, c);
+            project_px<FMA>(T, c[0], c[1], c[2], c[3], gx, gy);
+            if (go) go[p] = make_float2(gx, gy);
+            splat_px<uint8_t>(m, gx, gy, W, HW, 0, (uint8_t)1);
+        }
+    }
+}
+
+// Inverse warp: camera pixel -> projector pixel; samples the coded pattern and the projector-frame
+// scene coordinates (ray_x, ray_y, z_p) with the same four taps and composites both with the
+// visibility mask.
+template <bool FMA>
+__global__ __launch_bounds__(NT) void capture_sample_kernel(const float* __restrict__ z_c,
+                                                            const float* __restrict__ ray_x,
+                                                            const float* __restrict__ ray_y,
+                                                            const float* __restrict__ Tm, const float* __restrict__ Ip,
+                                                            const float* __restrict__ z_p,
+                                                            const uint8_t* __restrict__ mask_u8, int H, int W,
+                                                            float* __restrict__ grid, float* __restrict__ Ic,
+                                                            float* __restrict__ xyz) {
+    const int b = blockIdx.y;
+    const long HW = (long)H * W;
+    const long p0 = lane_first_pixel();
+    const float* T = Tm + (long)b * 16;
+    const float* zb = z_c + (long)b * HW;
+    const float* img = Ip + (long)b * HW;
+    const float* zp = z_p + (long)b * HW;
+    const uint8_t* mk = mask_u8 + (long)b * HW;
+    float z[PPL], mv[PPL];
+#pragma unroll
+    for (int i = 0; i < PPL; ++i) {
+        const long p = p0 + 64 * i;
+        if (p < HW) {
+            z[i] = zb[p];
+            mv[i] = (float)mk[p];
+        }
+    }
+    float gx[PPL], gy[PPL], i00[PPL], i01[PPL], i10[PPL], i11[PPL], z00[PPL], z01[PPL], z10[PPL], z11[PPL];
+    float rx0[PPL], rx1[PPL], ry0[PPL], ry1[PPL];
+    Taps t[PPL];
+#pragma unroll
+    for (int i = 0; i < PPL; ++i) {
+        const long p = p0 + 64 * i;
+        if (p < HW) {
+            float c[4];
+            point_of(z[i], ray_x, ray_y, (unsigned)p, (unsigned)W, c);
+            project_px<FMA>(T, c[0], c[1], c[2], c[3], gx[i], gy[i]);
+            t[i] = make_taps(gx[i], gy[i], H, W);
+            const unsigned a00 = (unsigned)t[i].y0 * W + t[i].x0, a01 = (unsigned)t[i].y1 * W + t[i].x0;
+            const unsigned a10 = (unsigned)t[i].y0 * W + t[i].x1, a11 = (unsigned)t[i].y1 * W + t[i].x1;
+            i00[i] = ld_at(img, a00); i01[i] = ld_at(img, a01); i10[i] = ld_at(img, a10); i11[i] = ld_at(img, a11);
+            z00[i] = ld_at(zp, a00); z01[i] = ld_at(zp, a01); z10[i] = ld_at(zp, a10); z11[i] = ld_at(zp, a11);
+            rx0[i] = ray_x[t[i].x0]; rx1[i] = ray_x[t[i].x1];
+            ry0[i] = ray_y[t[i].y0]; ry1[i] = ray_y[t[i].y1];
+        }
+    }
+    float2* go = grid ? reinterpret_cast<float2*>(grid) + (long)b * HW : nullptr;
+    float* oo = Ic + (long)b * HW;
+    float* xo = xyz + (long)b * HW * 3;
+#pragma unroll
+    for (int i = 0; i < PPL; ++i) {
+        const long p = p0 + 64 * i;
+        if (p < HW) {
+            if (go) go[p] = make_float2(gx[i], gy[i]);
+            oo[p] = __fmul_rn(blend(t[i], i00[i], i01[i], i10[i], i11[i]), mv[i]);
+            xo[p * 3 + 0] = __fmul_rn(blend(t[i], rx0[i], rx0[i], rx1[i], rx1[i]), mv[i]);
+            xo[p * 3 + 1] = __fmul_rn(blend(t[i], ry0[i], ry1[i], ry0[i], ry1[i]), mv[i]);
+            xo[p * 3 + 2] = __fmul_rn(blend(t[i], z00[i], z01[i], z10[i], z11[i]), mv[i]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// sensor model: exposure offset + read noise, per-image peak normalisation, gain, clipping
+// ---------------------------------------------------------------------------------------
+constexpr int POST_MAX_CHUNKS = 256;      // partial maxima per image
+constexpr int POST_PX_PER_CHUNK = 4096;
+
+// torch.max's ordering: a NaN wins and then stays.
+__device__ __forceinline__ float max_nan(float m, float e) { return (e > m || e != e) ? e : m; }
+
+__device__ __forceinline__ float exposed(float ic, float off005, float g) {
+    return __fadd_rn(__fadd_rn(ic, off005), __fmul_rn(g, 0.005f));
+}
+
+__device__ __forceinline__ float block_max_nan(float m, float* sh) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max_nan(m, __shfl_xor(m, o, 64));
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) sh[wave] = m;
+    __syncthreads();
+    float r = sh[0];
+#pragma unroll
+    for (int w = 1; w < NT / 64; ++w) r = max_nan(r, sh[w]);
+    return r;
+}
+
+static inline int post_chunks(long HW) {
+    const long n = (HW + POST_PX_PER_CHUNK - 1) / POST_PX_PER_CHUNK;
+    return (int)(n < 1 ? 1 : (n > POST_MAX_CHUNKS ? POST_MAX_CHUNKS : n));
+}
+// pixels per chunk, a multiple of 4 so that chunks of a 4-divisible image start on 16 bytes
+static inline long post_span(long HW, int chunks) { return ((HW + 4L * chunks - 1) / (4L * chunks)) * 4; }
+
+template <int VEC>
+__global__ __launch_bounds__(NT) void capture_peak_kernel(const float* __restrict__ Ic, const float* __restrict__ offset,
+                                                          const float* __restrict__ gauss, long HW, long span,
+                                                          float* __restrict__ partial) {
+    __shared__ float sh[NT / 64];
+    const int b = blockIdx.y;
+    const long lo = (long)blockIdx.x * span;
+    const long hi = lo + span < HW ? lo + span : HW;
+    const float off005 = __fmul_rn(offset[b], 0.05f);
+    const float* ic = Ic + (long)b * HW;
+    const float* g = gauss + (long)b * HW;
+    float m = -INFINITY;
+    if (VEC == 4) {
+        for (long p = lo + 4L * threadIdx.x; p < hi; p += 4L * NT) {
+            const float4 a = *reinterpret_cast<const float4*>(ic + p);
+            const float4 n = *reinterpret_cast<const float4*>(g + p);
+            m = max_nan(m, exposed(a.x, off005, n.x));
+            m = max_nan(m, exposed(a.y, off005, n.y));
+            m = max_nan(m, exposed(a.z, off005, n.z));
+            m = max_nan(m, exposed(a.w, off005, n.w));
+        }
+    } else {
+        for (long p = lo + threadIdx.x; p < hi; p += NT) m = max_nan(m, exposed(ic[p], off005, g[p]));
+    }
+    m = block_max_nan(m, sh);
+    if (threadIdx.x == 0) partial[(long)b * gridDim.x + blockIdx.x] = m;
+}
+
+__device__ __forceinline__ void sensor_px(float ic, float off005, float g, float peak, float gain, float vis,
+                                          float& scaled, float& valid) {
+    const float e = exposed(ic, off005, g);
+    float s = __fmul_rn(e / peak, gain);
+    s = s < 0.0f ? 0.0f : s;            // clamp keeps a NaN, like torch.clamp
+    s = s > 1.0f ? 1.0f : s;
+    scaled = s;
+    valid = __fmul_rn(s > 0.05f ? 1.0f : 0.0f, vis);
+}
+
+template <int VEC>
+__global__ __launch_bounds__(NT) void capture_sensor_kernel(const float* __restrict__ Ic, const float* __restrict__ offset,
+                                                            const float* __restrict__ gauss,
+                                                            const float* __restrict__ scale,
+                                                            const uint8_t* __restrict__ mask_u8,
+                                                            const float* __restrict__ partial, long HW, long span,
+                                                            float* __restrict__ Ic_scaled, float* __restrict__ Ic_mask) {
+    __shared__ float sh[NT / 64];
+    const int b = blockIdx.y;
+    const int chunks = gridDim.x;
+    float m = -INFINITY;
+    for (int c = threadIdx.x; c < chunks; c += NT) m = max_nan(m, partial[(long)b * chunks + c]);
+    const float peak = block_max_nan(m, sh);
+    const float off005 = __fmul_rn(offset[b], 0.05f);
+    const float gain = __fadd_rn(__fmul_rn(scale[b], 0.3f), 0.7f);
+    const long lo = (long)blockIdx.x * span;
+    const long hi = lo + span < HW ? lo + span : HW;
+    const float* ic = Ic + (long)b * HW;
+    const float* g = gauss + (long)b * HW;
+    const uint8_t* mk = mask_u8 + (long)b * HW;
+    float* so = Ic_scaled + (long)b * HW;
+    float* mo = Ic_mask + (long)b * HW;
+    if (VEC == 4) {
+        for (long p = lo + 4L * threadIdx.x; p < hi; p += 4L * NT) {
+            const float4 a = *reinterpret_cast<const float4*>(ic + p);
+            const float4 n = *reinterpret_cast<const float4*>(g + p);
+            const uchar4 v = *reinterpret_cast<const uchar4*>(mk + p);
+            float4 s, w;
+            sensor_px(a.x, off005, n.x, peak, gain, (float)v.x, s.x, w.x);
+            sensor_px(a.y, off005, n.y, peak, gain, (float)v.y, s.y, w.y);
+            sensor_px(a.z, off005, n.z, peak, gain, (float)v.z, s.z, w.z);
+            sensor_px(a.w, off005, n.w, peak, gain, (float)v.w, s.w, w.w);
+            *reinterpret_cast<float4*>(so + p) = s;
+            *reinterpret_cast<float4*>(mo + p) = w;
+        }
+    } else {
+        for (long p = lo + threadIdx.x; p < hi; p += NT)
+            sensor_px(ic[p], off005, g[p], peak, gain, (float)mk[p], so[p], mo[p]);
+    }
+}
+
+}  // namespace fc3d
+
+using namespace fc3d;
+
+extern "C" int fc3d_reflectance_fwd(void* stream, const float* I, int64_t i_sb, const float* z, int B, int H, int W,
+                                    float* out) {
+    if (!I || !z || !out || i_sb < 0) return FC3D_EINVAL;
+    if (int e = check_img(B, H, W)) return e;
+    FC3D_LAUNCH("reflectance", reflectance_kernel, dim3(cdiv((long)H * W, NT), B), dim3(NT), 0, (hipStream_t)stream, I,
+                (long)i_sb, z, H, W, out);
+    return FC3D_OK;
+}
+
+extern "C" int fc3d_capture_warp_fwd(void* stream, const float* Ip, const float* z_p, const float* z_c,
+                                     const float* ray_x, const float* ray_y, const float* T_p2c, const float* T_c2p,
+                                     int B, int H, int W, float* Ic_masked, float* xyz_cview, uint8_t* mask_u8,
+                                     int mask_is_clear, float* grid_p2c, float* grid_c2p) {
+    if (!Ip || !z_p || !z_c || !ray_x || !ray_y || !T_p2c || !T_c2p || !Ic_masked || !xyz_cview || !mask_u8)
+        return FC3D_EINVAL;
+    if (int e = check_img(B, H, W)) return e;
+    if ((reinterpret_cast<uintptr_t>(grid_p2c) & 7u) || (reinterpret_cast<uintptr_t>(grid_c2p) & 7u)) return FC3D_EALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 g(cdiv((long)H * W, PX_PER_BLOCK), B), blk(NT);
+    if (!mask_is_clear) {
+        if (int e = zero_fill(s, mask_u8, (size_t)B * H * W)) return e;
+    }
+    if (use_fma(H, W)) {
+        FC3D_LAUNCH("capture_project_splat", capture_project_kernel<true>, g, blk, 0, s, z_p, ray_x, ray_y, T_p2c, H, W,
+                    grid_p2c, mask_u8);
+        FC3D_LAUNCH("capture_sample", capture_sample_kernel<true>, g, blk, 0, s, z_c, ray_x, ray_y, T_c2p, Ip, z_p,
+                    (const uint8_t*)mask_u8, H, W, grid_c2p, Ic_masked, xyz_cview);
+    } else {
+        FC3D_LAUNCH("capture_project_splat", capture_project_kernel<false>, g, blk, 0, s, z_p, ray_x, ray_y, T_p2c, H, W,
+                    grid_p2c, mask_u8);
+        FC3D_LAUNCH("capture_sample", capture_sample_kernel<false>, g, blk, 0, s, z_c, ray_x, ray_y, T_c2p, Ip, z_p,
+                    (const uint8_t*)mask_u8, H, W, grid_c2p, Ic_masked, xyz_cview);
+    }
+    return FC3D_OK;
+}
+
+extern "C" size_t fc3d_capture_post_workspace(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)B * post_chunks((long)H * W) * sizeof(float);
+}
+
+extern "C" int fc3d_capture_post(void* stream, const float* Ic, const float* offset, const float* gauss,
+                                 const float* scale, const uint8_t* mask_u8, int B, int H, int W, float* Ic_scaled,
+                                 float* Ic_mask, void* workspace) {
+    if (!Ic || !offset || !gauss || !scale || !mask_u8 || !Ic_scaled || !Ic_mask || !workspace) return FC3D_EINVAL;
+    if (int e = check_img(B, H, W)) return e;
+    if (!aligned4(workspace)) return FC3D_EALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    const long HW = (long)H * W;
+    const int chunks = post_chunks(HW);
+    const long span = post_span(HW, chunks);
+    const bool vec = HW % 4 == 0 && aligned16(Ic) && aligned16(gauss) && aligned16(Ic_scaled) && aligned16(Ic_mask) &&
+                     aligned4(mask_u8);
+    float* partial = (float*)workspace;
+    dim3 g(chunks, B), blk(NT);
+    if (vec) {
+        FC3D_LAUNCH("capture_peak", capture_peak_kernel<4>, g, blk, 0, s, Ic, offset, gauss, HW, span, partial);
+        FC3D_LAUNCH("capture_sensor", capture_sensor_kernel<4>, g, blk, 0, s, Ic, offset, gauss, scale, mask_u8,
+                    (const float*)partial, HW, span, Ic_scaled, Ic_mask);
+    } else {
+        FC3D_LAUNCH("capture_peak", capture_peak_kernel<1>, g, blk, 0, s, Ic, offset, gauss, HW, span, partial);
+        FC3D_LAUNCH("capture_sensor", capture_sensor_kernel<1>, g, blk, 0, s, Ic, offset, gauss, scale, mask_u8,
+                    (const float*)partial, HW, span, Ic_scaled, Ic_mask);
+    }
+    return FC3D_OK;
+}

@@ -90,4 +90,34 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Clears `bytes` bytes at p with an ordinary kernel launch.  (A memset call is avoided on purpose:
+// replayed from a captured stream graph it was seen to leave part of its range untouched, while a
+// kernel node is ordered like every other launch of the step.)
+static __global__ __launch_bounds__(256) void zero_fill_kernel(uint4* __restrict__ body, long n16,
+                                                               uint8_t* __restrict__ head, int nhead,
+                                                               uint8_t* __restrict__ tail, int ntail) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) body[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (blockIdx.x == 0) {
+        if ((int)threadIdx.x < nhead) head[threadIdx.x] = 0;
+        if ((int)threadIdx.x < ntail) tail[threadIdx.x] = 0;
+    }
+}
+
+static inline int zero_fill(hipStream_t s, void* p, size_t bytes) {
+    if (bytes == 0) return FC3D_OK;
+    uint8_t* head = static_cast<uint8_t*>(p);
+    size_t nhead = (16 - (reinterpret_cast<uintptr_t>(p) & 15u)) & 15u;
+    if (nhead > bytes) nhead = bytes;
+    uint4* body = reinterpret_cast<uint4*>(head + nhead);
+    const long n16 = (long)((bytes - nhead) / 16);
+    uint8_t* tail = reinterpret_cast<uint8_t*>(body + n16);
+    const int ntail = (int)((bytes - nhead) % 16);
+    long blocks = (n16 + 256 * 4 - 1) / (256 * 4);          // about four 16-byte stores per lane
+    blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+    FC3D_LAUNCH("zero_fill", zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, s, body, n16, head, (int)nhead, tail,
+                ntail);
+    return FC3D_OK;
+}
+
 }  // namespace fc3d

@@ -7,11 +7,9 @@
 // Arithmetic that decides an integer (floor/ceil/round of a projected coordinate) follows
 // the operation order of the reference's tensor ops exactly; explicit __fmul_rn/__fadd_rn
 // and fmaf keep the compiler from re-associating or contracting it.
-#include "fc3d_common.h"
+#include "geom_dev.h"
 
 namespace fc3d {
-
-constexpr int NT = 256;
 
 // ---------------------------------------------------------------------------------------
 // per-sample matrices
@@ -105,16 +103,6 @@ enum CoordLayout { kStrided = 0, kPlanarFlat = 1, kPixel4Flat = 2 };
 // kPixel4Flat : dense [H][W][4] (what z2pointcloud's permuted view points at): one aligned float4 per pixel
 // kStrided    : any other view; (y, x) are recovered from p
 
-// Every lane owns PPL pixels that are 64 apart inside its wavefront's run of 64*PPL consecutive
-// pixels, so each load/store/gather instruction of a wavefront touches 64 neighbouring pixels.
-// Two per lane measured best at 32x512x512 (4: 45/54 us for projection/sampling, 2: 41/50, 1: 43/52).
-constexpr int PPL = 2;
-constexpr int PX_PER_BLOCK = NT * PPL;
-
-__device__ __forceinline__ long lane_first_pixel() {
-    return (long)blockIdx.x * PX_PER_BLOCK + (threadIdx.x >> 6) * (64 * PPL) + (threadIdx.x & 63);
-}
-
 template <int LAYOUT>
 __device__ __forceinline__ void load_coord(const float* __restrict__ base, long sc, long sh, long sw, long p, int W,
                                            float c[4]) {
@@ -128,70 +116,6 @@ __device__ __forceinline__ void load_coord(const float* __restrict__ base, long 
         const long y = p / W, x = p - y * W;
 #pragma unroll
         for (int k = 0; k < 4; ++k) c[k] = base[k * sc + y * sh + x * sw];
-    }
-}
-
-// Row of T times a column.  torch.matmul([B,4,4],[B,4,HW]) runs a k-ordered fused
-// multiply-add chain (vendor sgemm) once 16*HW >= 400, and an unfused loop below that.
-template <bool FMA>
-__device__ __forceinline__ float row_dot(const float* t, float c0, float c1, float c2, float c3) {
-    if (FMA) {
-        float a = __fmul_rn(t[0], c0);
-        a = fmaf(t[1], c1, a);
-        a = fmaf(t[2], c2, a);
-        a = fmaf(t[3], c3, a);
-        return a;
-    } else {
-        float a = __fmul_rn(t[0], c0);
-        a = __fadd_rn(a, __fmul_rn(t[1], c1));
-        a = __fadd_rn(a, __fmul_rn(t[2], c2));
-        a = __fadd_rn(a, __fmul_rn(t[3], c3));
-        return a;
-    }
-}
-
-template <bool FMA>
-__device__ __forceinline__ void project_px(const float* T, float c0, float c1, float c2, float c3, float& gx,
-                                           float& gy) {
-    const float xu = row_dot<FMA>(T + 0, c0, c1, c2, c3);
-    const float yu = row_dot<FMA>(T + 4, c0, c1, c2, c3);
-    const float zu = row_dot<FMA>(T + 8, c0, c1, c2, c3);
-    const float den = __fadd_rn(zu, 1e-10f);
-    gx = xu / den;
-    gy = yu / den;
-}
-
-// Marks the pixels a projected point touches (gen_visible_mask).  The flat index is formed
-// in fp32 and only the flat index is range-checked, exactly like the reference, so an x
-// outside the row wraps into the neighbouring row.  Idempotent byte/float stores of "1"
-// need no atomics and give a bit-exact, order-independent mask.
-template <typename MaskT>
-__device__ __forceinline__ void mark(MaskT* __restrict__ m, float xi, float yW, long HW, MaskT one) {
-    const float f = __fadd_rn(xi, yW);           // integer-valued (or NaN/Inf): a sum of floor/ceil/round results
-    if (HW <= (1L << 24)) {
-        // every valid index is exactly representable, so the range test can stay in fp32 and the
-        // index in 32 bits (NaN fails both comparisons)
-        if (f >= 0.0f && f < (float)HW) m[(int)f] = one;
-    } else {
-        if (!(fabsf(f) < 9.0e18f)) return;       // NaN / Inf / beyond int64: the reference's cast yields a negative index
-        const long idx = (long)f;
-        if (idx >= 0 && idx < HW) m[idx] = one;
-    }
-}
-
-template <typename MaskT>
-__device__ __forceinline__ void splat_px(MaskT* __restrict__ m, float gx, float gy, int W, long HW, int method,
-                                         MaskT one) {
-    const float Wf = (float)W;
-    if (method == 0) {
-        const float fx = floorf(gx), cx = ceilf(gx);
-        const float fyW = __fmul_rn(floorf(gy), Wf), cyW = __fmul_rn(ceilf(gy), Wf);
-        mark(m, fx, fyW, HW, one);
-        mark(m, fx, cyW, HW, one);
-        mark(m, cx, fyW, HW, one);
-        mark(m, cx, cyW, HW, one);
-    } else {
-        mark(m, rintf(gx), __fmul_rn(rintf(gy), Wf), HW, one);
     }
 }
 
@@ -228,37 +152,6 @@ __global__ __launch_bounds__(NT) void project_kernel(const float* __restrict__ c
 // ---------------------------------------------------------------------------------------
 // bilinear sampling
 // ---------------------------------------------------------------------------------------
-struct Taps {
-    int x0, x1, y0, y1;
-    float wx0, wx1, wy0, wy1;
-};
-// Corners are clamped first and the weights are taken from the CLAMPED corners
-// (geometry_pytorch.py:136-145): out-of-image samples cancel to ~0, and an exact integer
-// coordinate on the last row/column gets weight 0.  fmaxf/fminf drop a NaN so indices stay
-// in range (the reference would raise on a NaN coordinate); the weights keep the NaN.
-__device__ __forceinline__ Taps make_taps(float gx, float gy, int Hs, int Ws) {
-    const float xm = (float)(Ws - 1), ym = (float)(Hs - 1);
-    const float fx = floorf(gx), fy = floorf(gy);
-    const float x0 = fminf(fmaxf(fx, 0.0f), xm), x1 = fminf(fmaxf(__fadd_rn(fx, 1.0f), 0.0f), xm);
-    const float y0 = fminf(fmaxf(fy, 0.0f), ym), y1 = fminf(fmaxf(__fadd_rn(fy, 1.0f), 0.0f), ym);
-    Taps t;
-    t.wx0 = __fsub_rn(x1, gx);
-    t.wx1 = __fsub_rn(gx, x0);
-    t.wy0 = __fsub_rn(y1, gy);
-    t.wy1 = __fsub_rn(gy, y0);
-    t.x0 = (int)x0; t.x1 = (int)x1; t.y0 = (int)y0; t.y1 = (int)y1;
-    return t;
-}
-
-__device__ __forceinline__ float blend(const Taps& t, float i00, float i01, float i10, float i11) {
-    // iab = image at (x_a, y_b); same products and left-to-right sum as geometry_pytorch.py:171-176
-    float o = __fmul_rn(__fmul_rn(t.wx0, t.wy0), i00);
-    o = __fadd_rn(o, __fmul_rn(__fmul_rn(t.wx0, t.wy1), i01));
-    o = __fadd_rn(o, __fmul_rn(__fmul_rn(t.wx1, t.wy0), i10));
-    o = __fadd_rn(o, __fmul_rn(__fmul_rn(t.wx1, t.wy1), i11));
-    return o;
-}
-
 // warp_p2c's inverse warp: project coord_c, sample the single-channel pattern, composite
 // with the visibility mask.
 template <int LAYOUT, bool FMA>
@@ -891,15 +784,6 @@ static int pick_layout(const float* coord, int64_t sc, int64_t sh, int64_t sw, i
     return kStrided;
 }
 
-static int check_img(int B, int H, int W) {
-    if (B <= 0 || H <= 0 || W <= 0) return FC3D_EINVAL;
-    if ((long)B * H * W >= (1L << 31) || B > 65535 || H > 65535) return FC3D_ERANGE;
-    return FC3D_OK;
-}
-
-// 16*H*W >= 400 selects torch's sgemm (fused multiply-add) path for [B,4,4]x[B,4,HW].
-static inline bool use_fma(int H, int W) { return 16L * H * W >= 400; }
-
 #define FC3D_DISPATCH_LAYOUT(NAME, KERNEL, layout, fma, ...)                                                     \
     do {                                                                                                   \
         if (fma) {                                                                                         \
@@ -1020,7 +904,7 @@ extern "C" int fc3d_bilinear_bwd_img(void* stream, const float* g_out, const flo
     if (reinterpret_cast<uintptr_t>(grid) & 7u) return FC3D_EALIGN;
     hipStream_t s = (hipStream_t)stream;
     if (C != 1) {
-        FC3D_HIP(hipMemsetAsync(g_img, 0, (size_t)B * Hs * Ws * C * sizeof(float), s));
+        if (int e = zero_fill(s, g_img, (size_t)B * Hs * Ws * C * sizeof(float))) return e;
         const long np = (long)Ht * Wt;
         FC3D_LAUNCH("bilinear_bwd_img_atomic", bilinear_bwd_img_atomic_kernel, dim3(cdiv(np, NT), B), dim3(NT), 0, s, g_out, grid, mask_u8,
                            Hs, Ws, C, np, g_img);
@@ -1031,7 +915,7 @@ extern "C" int fc3d_bilinear_bwd_img(void* stream, const float* g_out, const flo
     const int ntiles = wave_tiles(Ht, Wt, &tiles_x);
     const dim3 gs(cdiv(ntiles, NT / 64), B), blk(NT);
     if (!workspace) {   // window sums go straight into the zeroed gradient image with float atomics
-        FC3D_HIP(hipMemsetAsync(g_img, 0, (size_t)B * Hs * Ws * sizeof(float), s));
+        if (int e = zero_fill(s, g_img, (size_t)B * Hs * Ws * sizeof(float))) return e;
         FC3D_LAUNCH("bilinear_bwd_img_scatter", bilinear_bwd_img_scatter_kernel<true>, gs, blk, 0, s, g_out, grid, mask_u8, Hs, Ws, Ht, Wt, tiles_x,
                        ntiles, (TileMeta*)nullptr, (float*)nullptr, g_img);
         return FC3D_OK;
@@ -1058,8 +942,12 @@ extern "C" int fc3d_visible_mask(void* stream, const float* grid, int B, int H, 
     if (reinterpret_cast<uintptr_t>(grid) & 7u) return FC3D_EALIGN;
     hipStream_t s = (hipStream_t)stream;
     const size_t n = (size_t)B * H * W;
-    if (mask_f32) FC3D_HIP(hipMemsetAsync(mask_f32, 0, n * sizeof(float), s));
-    if (mask_u8) FC3D_HIP(hipMemsetAsync(mask_u8, 0, n, s));
+    if (mask_f32) {
+        if (int e = zero_fill(s, mask_f32, n * sizeof(float))) return e;
+    }
+    if (mask_u8) {
+        if (int e = zero_fill(s, mask_u8, n)) return e;
+    }
     const long HW = (long)H * W;
     FC3D_LAUNCH("visible_mask", visible_mask_kernel, dim3(cdiv(HW, NT), B), dim3(NT), 0, s, grid, H, W, method, mask_f32,
                        mask_u8);
@@ -1081,7 +969,9 @@ extern "C" int fc3d_warp_p2c_fwd(void* stream, const float* Ip, const float* coo
     hipStream_t s = (hipStream_t)stream;
     const bool fma = use_fma(H, W);
     dim3 g(cdiv((long)H * W, PX_PER_BLOCK), B), blk(NT);
-    if (!mask_is_clear) FC3D_HIP(hipMemsetAsync(mask_u8, 0, (size_t)B * H * W, s));
+    if (!mask_is_clear) {
+        if (int e = zero_fill(s, mask_u8, (size_t)B * H * W)) return e;
+    }
     {
         const int layout = pick_layout(coord_p, p_sc, p_sh, p_sw, W);
 #define ARGS coord_p, (long)p_sb, (long)p_sc, (long)p_sh, (long)p_sw, T_p2c, H, W, grid_p2c, mask_u8

@@ -446,3 +446,71 @@ class ReprojectFn(torch.autograd.Function):
                                            im.shape[2], gp.data_ptr()),
                    "fc3d_reproject_bwd")
         return gp, None, None, None, None
+
+
+# --------------------------------------------------------------------------- #
+# capture simulator (forward only)
+# --------------------------------------------------------------------------- #
+def _plane(t: torch.Tensor, B: int, H: int, W: int, what: str) -> torch.Tensor:
+    if t.numel() != B * H * W:
+        raise ValueError(f"{what}: expected {B}x{H}x{W} values, got shape {tuple(t.shape)}")
+    return _dense(t)
+
+
+def reflectance(I: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
+    """I [B or 1,H,W,1] * (0.8 cos(atan(|grad z| / 100um)) + 0.2), z [B,H,W,1]; no gradient."""
+    dev = _need_gpu(I, z)
+    B, H, W = z.shape[0], z.shape[1], z.shape[2]
+    if I.shape[0] not in (1, B) or I.numel() != I.shape[0] * H * W:
+        raise ValueError(f"pattern of shape {tuple(I.shape)} does not match depth {tuple(z.shape)}")
+    I, z = _dense(I.detach()), _plane(z.detach(), B, H, W, "z")
+    out = torch.empty((B, H, W, 1), dtype=torch.float32, device=dev)
+    with _on_device(dev):
+        _check(_lib.fc3d_reflectance_fwd(_stream(), I.data_ptr(), H * W if I.shape[0] == B and B > 1 else 0,
+                                         z.data_ptr(), B, H, W, out.data_ptr()), "fc3d_reflectance_fwd")
+    return out
+
+
+def capture_warp(Ip, z_p, z_c, ray_x, ray_y, T_p2c, T_c2p, zero_mask=None, want_grids=False):
+    """Ic_masked [B,H,W,1], xyz_cview [B,H,W,3], mask u8 [B,H,W] (and the two grids if asked)
+    from the coded pattern and the two depth maps; no gradient."""
+    dev = _need_gpu(Ip, z_p, z_c, ray_x, ray_y, T_p2c, T_c2p)
+    B, H, W = z_p.shape[0], z_p.shape[1], z_p.shape[2]
+    if ray_x.numel() != W or ray_y.numel() != H or T_p2c.numel() != 16 * B or T_c2p.numel() != 16 * B:
+        raise ValueError("ray table or transforms do not match the depth maps")
+    Ip, z_p, z_c = (_plane(t.detach(), B, H, W, n) for t, n in ((Ip, "Ip"), (z_p, "z_p"), (z_c, "z_c")))
+    Ic = torch.empty((B, H, W, 1), dtype=torch.float32, device=dev)
+    xyz = torch.empty((B, H, W, 3), dtype=torch.float32, device=dev)
+    mask = zero_mask if zero_mask is not None else torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+    if mask.dtype != torch.uint8 or mask.numel() != B * H * W or not mask.is_contiguous():
+        raise ValueError("zero_mask must be a dense uint8 [B,H,W] tensor")
+    gp = torch.empty((B, H, W, 2), dtype=torch.float32, device=dev) if want_grids else None
+    gc = torch.empty((B, H, W, 2), dtype=torch.float32, device=dev) if want_grids else None
+    with _on_device(dev):
+        _check(_lib.fc3d_capture_warp_fwd(_stream(), Ip.data_ptr(), z_p.data_ptr(), z_c.data_ptr(),
+                                          _dense(ray_x).data_ptr(), _dense(ray_y).data_ptr(),
+                                          _dense(T_p2c).data_ptr(), _dense(T_c2p).data_ptr(), B, H, W, Ic.data_ptr(),
+                                          xyz.data_ptr(), mask.data_ptr(), int(zero_mask is not None),
+                                          gp.data_ptr() if want_grids else None,
+                                          gc.data_ptr() if want_grids else None), "fc3d_capture_warp_fwd")
+    return (Ic, xyz, mask, gp, gc) if want_grids else (Ic, xyz, mask)
+
+
+def capture_post(Ic, offset, gauss, scale, mask_u8):
+    """(Ic_scaled, Ic_mask) [B,H,W,1] of the sensor model from the warped image, the three noise
+    draws (offset, scale: B values; gauss: B*H*W values) and the visibility mask; no gradient."""
+    dev = _need_gpu(Ic, offset, gauss, scale)
+    B, H, W = Ic.shape[0], Ic.shape[1], Ic.shape[2]
+    if offset.numel() != B or scale.numel() != B:
+        raise ValueError("offset and scale hold one value per sample")
+    if mask_u8.dtype != torch.uint8 or mask_u8.numel() != B * H * W or mask_u8.device != dev:
+        raise ValueError("mask_u8 must be the warp's uint8 [B,H,W] visibility mask")
+    Ic, gauss = _plane(Ic.detach(), B, H, W, "Ic"), _plane(gauss, B, H, W, "gauss")
+    scaled = torch.empty((B, H, W, 1), dtype=torch.float32, device=dev)
+    valid = torch.empty((B, H, W, 1), dtype=torch.float32, device=dev)
+    ws = torch.empty(max(1, _lib.fc3d_capture_post_workspace(B, H, W) // 4), dtype=torch.float32, device=dev)
+    with _on_device(dev):
+        _check(_lib.fc3d_capture_post(_stream(), Ic.data_ptr(), _dense(offset).data_ptr(), gauss.data_ptr(),
+                                      _dense(scale).data_ptr(), _dense(mask_u8).data_ptr(), B, H, W,
+                                      scaled.data_ptr(), valid.data_ptr(), ws.data_ptr()), "fc3d_capture_post")
+    return scaled, valid

@@ -193,6 +193,45 @@ int fc3d_reproject_bwd(void *stream, const float *g_zc, const float *g_out, cons
                        float *g_zp);
 
 /* ------------------------------------------------------------------------ */
+/* the capture simulator around the path (forward_model, train_pytorch.py:     */
+/* 79-118; the reference runs it without gradients, so these are forward only)  */
+/* ------------------------------------------------------------------------ */
+
+/* withReflectance, utils_pytorch.py:251-280 (with image_gradients, :206-222):
+ * out = I * (0.8*cos(atan(|grad z| / 100e-6)) + 0.2), forward differences, zero on the
+ * last row / column.  I [B][H][W] with batch stride i_sb elements (0: one pattern for
+ * every sample); z, out [B][H][W].  Floating-point result (1e-6 relative of the composed
+ * tensor ops: cos(atan(t)) is evaluated as 1/sqrt(1+t^2)).                             */
+int fc3d_reflectance_fwd(void *stream, const float *I, int64_t i_sb, const float *z, int B, int H, int W,
+                         float *out);
+
+/* train_pytorch.py:86-87, 97, 107-116 in two launches: scene points from the two depth
+ * maps and the separable ray table (ray_x [W], ray_y [H]: pixel_to_ray_array's columns 0
+ * and 1, geometry_pytorch.py:15-41), warp_p2c (geometry_pytorch.py:255-281), and
+ * xyz_cview = bilinear_sampler(cat(xy, z_p), grid_c2p) * visible_mask.  Ip, z_p, z_c,
+ * Ic_masked [B][H][W]; xyz_cview [B][H][W][3]; mask_u8 [B][H][W] (the 'all' visibility
+ * mask, see fc3d_warp_p2c_fwd for mask_is_clear); grid_p2c / grid_c2p [B][H][W][2] are
+ * written only when not NULL.  Bit-identical to fc3d_points_fwd + fc3d_warp_p2c_fwd +
+ * fc3d_bilinear_fwd on the same inputs, without the scene points, the grids and the
+ * concatenated image passing through memory.                                            */
+int fc3d_capture_warp_fwd(void *stream, const float *Ip, const float *z_p, const float *z_c, const float *ray_x,
+                          const float *ray_y, const float *T_p2c, const float *T_c2p, int B, int H, int W,
+                          float *Ic_masked, float *xyz_cview, uint8_t *mask_u8, int mask_is_clear, float *grid_p2c,
+                          float *grid_c2p);
+
+/* The sensor model, train_pytorch.py:100-104 and :118, with the random draws passed in:
+ *   e = Ic + offset[b]*0.05 + gauss*0.005;  Ic_scaled = clamp(e / max_image(e) * (scale[b]*0.3 + 0.7), 0, 1);
+ *   Ic_mask = (Ic_scaled > 0.05) * visible_mask.
+ * offset, scale [B] (uniform draws in [0,1)), gauss [B][H][W] (standard normal draws),
+ * mask_u8 [B][H][W] from the warp; outputs [B][H][W] fp32.  Same operations in the same
+ * order as the tensor expression, so the results are bit-identical to it; a NaN in an
+ * image makes that image's maximum NaN, as torch.max does.  workspace: at least
+ * fc3d_capture_post_workspace bytes, 4-byte aligned, need not be initialised.            */
+size_t fc3d_capture_post_workspace(int B, int H, int W);
+int fc3d_capture_post(void *stream, const float *Ic, const float *offset, const float *gauss, const float *scale,
+                      const uint8_t *mask_u8, int B, int H, int W, float *Ic_scaled, float *Ic_mask, void *workspace);
+
+/* ------------------------------------------------------------------------ */
 /* optional per-kernel timing (no counterpart in the reference, which has no   */
 /* profiling hooks): while enabled every kernel launch of this library is       */
 /* bracketed by a HIP event pair on the launching stream.  fc3d_profile_report  */

@@ -29,7 +29,8 @@ def K_fn(W, H):
     return get_intrinsic
 
 
-def test_forward_model_and_reproj_vs_oracle(env, monkeypatch):
+@pytest.mark.parametrize("fused", [True, False], ids=["capture-kernels", "composed"])
+def test_forward_model_and_reproj_vs_oracle(env, monkeypatch, fused):
     G, O, capture, synth, orc = (env[k] for k in ("G", "O", "capture", "synth", "orc"))
     B, H, W, L, N = 2, 96, 128, 21, 64
     monkeypatch.setattr(G, "get_intrinsic", K_fn(W, H))
@@ -42,7 +43,7 @@ def test_forward_model_and_reproj_vs_oracle(env, monkeypatch):
     d = lambda a: torch.from_numpy(a).cuda()  # noqa: E731
     t = torch.from_numpy
     out = capture.forward_model(d(sc["z_p"]), d(sc["z_c"]), d(sc["pose_p2c"]), L, True, N,
-                                {k: d(v) for k, v in noise.items()})
+                                {k: d(v) for k, v in noise.items()}, fused=fused)
     Ic_s, Ic_m, xyz, xy, zc, zp, pose, zp_full, Ic, Ip_coded, Ic_s_full = out
     assert Ic_s.shape == (B, N, N, 1) and xyz.shape == (B, N, N, 3) and Ip_coded.shape == (B, H, W, 1)
 
@@ -81,6 +82,58 @@ def test_forward_model_and_reproj_vs_oracle(env, monkeypatch):
     (l1 + lz).backward()
     assert abs(float(loss) - float(l1 + lz)) < 1e-4 * abs(float(l1 + lz))
     assert rel_err(zhat.grad.cpu().numpy(), zh.grad.numpy()) < 2e-3      # L1 loss: sign flips at |diff|~0 pixels
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 96, 128), (3, 37, 53), (1, 4, 5), (1, 1, 1)])
+def test_capture_kernels_match_composed_operators(env, monkeypatch, B, H, W):
+    """The capture kernels against the operators they stand for, on the same device inputs:
+    warp straight from the depth maps == points + warp_p2c + bilinear_sampler (bit for bit, masks
+    and grids included); sensor model == the tensor expression evaluated by torch on the CPU
+    (IEEE division), bit for bit; shading within 1e-5 (it skips the atan/cos roundings)."""
+    G, capture, synth = env["G"], env["capture"], env["synth"]
+    from fc3d import ops
+    monkeypatch.setattr(G, "get_intrinsic", K_fn(W, H))
+    sc = synth.make_scene(B, H, W, 95)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    z_p, z_c, pose = d(sc["z_p"]), d(sc["z_c"]), d(sc["pose_p2c"])
+    rs = np.random.RandomState(96)
+    Ip = d(rs.uniform(0, 1, (B, H, W, 1)).astype(np.float32))
+
+    # shading
+    for pat in (Ip, Ip[:1]):
+        got = ops.reflectance(pat, z_p)
+        want = capture.with_reflectance(pat, z_p)
+        assert got.shape == want.shape
+        assert rel_err(got.cpu().numpy(), want.cpu().numpy()) < 1e-5
+
+    # warp from the depth maps
+    rays = G.pixel_to_ray_array(W, H)
+    coord_p = G.points_in_camera_coords(z_p, rays).permute(0, 3, 1, 2)
+    coord_c = G.points_in_camera_coords(z_c, rays).permute(0, 3, 1, 2)
+    Ic_ref, gp_ref, gc_ref = G.warp_p2c(Ip, coord_p, coord_c, pose)
+    vis_ref = G.gen_visible_mask(gp_ref, "all")
+    xy = capture._rays_xy(H, W, z_p.device).unsqueeze(0).expand(B, -1, -1, -1)
+    xyz_ref = G.bilinear_sampler(torch.cat([xy, z_p], dim=-1), gc_ref) * vis_ref
+    rx, ry = G._separable_rays(W, H, z_p.device)
+    T_p2c, T_c2p, _ = ops.pose_transforms(pose, G._intrinsics_for(B, z_p.device), want_fwd=True, want_inv=True)
+    Ic, xyz, mask, gp, gc = ops.capture_warp(Ip, z_p, z_c, rx, ry, T_p2c, T_c2p, want_grids=True)
+    assert torch.equal(gp, gp_ref) and torch.equal(gc, gc_ref)
+    assert torch.equal(mask.view(B, H, W, 1).float(), vis_ref)
+    assert torch.equal(Ic, Ic_ref)
+    assert torch.equal(xyz, xyz_ref)
+    Ic2, xyz2, mask2 = ops.capture_warp(Ip, z_p, z_c, rx, ry, T_p2c, T_c2p)      # grids not asked for
+    assert torch.equal(Ic2, Ic) and torch.equal(xyz2, xyz) and torch.equal(mask2, mask)
+
+    # sensor model
+    off, sca = rs.rand(B, 1, 1, 1).astype(np.float32), rs.rand(B, 1, 1, 1).astype(np.float32)
+    gau = rs.randn(B, H, W, 1).astype(np.float32)
+    scaled, valid = ops.capture_post(Ic, d(off), d(gau), d(sca), mask)
+    t = torch.from_numpy
+    Ie = Ic.cpu() + t(off) * 0.05 + t(gau) * 0.005
+    Is = torch.clamp(Ie / Ie.amax(dim=(1, 2), keepdim=True) * (t(sca) * 0.3 + 0.7), 0.0, 1.0)
+    Im = (Is > 0.05).float() * vis_ref.cpu()
+    assert torch.equal(scaled.cpu(), Is)
+    assert torch.equal(valid.cpu(), Im)
 
 
 def test_train_step_runs(env, monkeypatch):
@@ -134,10 +187,12 @@ def test_graph_replay_matches_eager(env, monkeypatch):
     assert torch.equal(Ic_g, Ic_e)
     assert float((gr_g - gr_e).abs().max()) <= 1e-5 * float(gr_e.abs().max())
     new = np.random.RandomState(7).uniform(0, 1, wl["pattern"].shape).astype(np.float32)
-    with torch.no_grad():
-        pat.copy_(d(new))
-    Ic_g, gr_g = gf.replay()
-    Ic_e, gr_e = eager(new)
-    torch.cuda.synchronize()
-    assert torch.equal(Ic_g, Ic_e)
-    assert float((gr_g - gr_e).abs().max()) <= 1e-5 * float(gr_e.abs().max())
+    # replays issued right behind other work on the stream, with the inputs changing every time
+    for src in (new, new, wl["pattern"], new, wl["pattern"]):
+        with torch.no_grad():
+            pat.copy_(d(src))
+        Ic_g, gr_g = gf.replay()
+        Ic_e, gr_e = eager(src)
+        torch.cuda.synchronize()
+        assert torch.equal(Ic_g, Ic_e)
+        assert float((gr_g - gr_e).abs().max()) <= 1e-5 * float(gr_e.abs().max())
