@@ -18,21 +18,54 @@ namespace fc3d {
 // I * (0.8 cos(atan(|grad z| / 100 um)) + 0.2) with forward differences that are zero on the last
 // row / column.  cos(atan(t)) is evaluated as 1/sqrt(1 + t^2): the same function without the two
 // transcendental roundings (result within 1e-6 relative of the composed form).
+__device__ __forceinline__ float shade(float I, float z0, float zr, float zb, bool has_r, bool has_b) {
+    const float dx = has_r ? __fsub_rn(zr, z0) : 0.0f;
+    const float dy = has_b ? __fsub_rn(zb, z0) : 0.0f;
+    const float t = sqrtf(__fadd_rn(__fmul_rn(dy, dy), __fmul_rn(dx, dx))) / 100e-6f;
+    const float c = 1.0f / sqrtf(__fadd_rn(1.0f, __fmul_rn(t, t)));
+    return __fmul_rn(I, __fadd_rn(__fmul_rn(c, 0.8f), 0.2f));
+}
+
+// VEC = 4 (W divisible by 4, 16-byte aligned planes): four pixels of a row per lane, the row below as a
+// second 16-byte load and the right neighbour of the last pixel from the next lane (one extra load
+// only where the next lane is not the next group of the same row).
+template <int VEC>
 __global__ __launch_bounds__(NT) void reflectance_kernel(const float* __restrict__ I, long i_sb,
                                                          const float* __restrict__ z, int H, int W,
                                                          float* __restrict__ out) {
     const int b = blockIdx.y;
     const unsigned HW = (unsigned)H * (unsigned)W;
-    const unsigned p = blockIdx.x * NT + threadIdx.x;
-    if (p >= HW) return;
-    const unsigned y = p / (unsigned)W, x = p - y * (unsigned)W;
     const float* zb = z + (long)b * HW;
-    const float z0 = zb[p];
-    const float dx = (x + 1 < (unsigned)W) ? __fsub_rn(zb[p + 1], z0) : 0.0f;
-    const float dy = (y + 1 < (unsigned)H) ? __fsub_rn(zb[p + W], z0) : 0.0f;
-    const float t = sqrtf(__fadd_rn(__fmul_rn(dy, dy), __fmul_rn(dx, dx))) / 100e-6f;
-    const float c = 1.0f / sqrtf(__fadd_rn(1.0f, __fmul_rn(t, t)));
-    out[(long)b * HW + p] = __fmul_rn(I[(long)b * i_sb + p], __fadd_rn(__fmul_rn(c, 0.8f), 0.2f));
+    const float* Ib = I + (long)b * i_sb;
+    float* ob = out + (long)b * HW;
+    if (VEC == 4) {
+        const unsigned p = (blockIdx.x * NT + threadIdx.x) * 4u;
+        const bool live = p < HW;
+        const unsigned q = live ? p : 0u;
+        const unsigned y = q / (unsigned)W, x = q - y * (unsigned)W;
+        const bool has_b = y + 1 < (unsigned)H;
+        const float4 z0 = ld_at(reinterpret_cast<const float4*>(zb), q >> 2);
+        const float4 z1 = has_b ? ld_at(reinterpret_cast<const float4*>(zb), (q + W) >> 2) : z0;
+        const float4 Iv = ld_at(reinterpret_cast<const float4*>(Ib), q >> 2);
+        // the next lane holds pixels q+4..q+7; valid as a right neighbour when it exists and is in the same row
+        float zn = __shfl_down(z0.x, 1, 64);
+        const bool has_r = x + 4 < (unsigned)W;
+        if (has_r && (threadIdx.x & 63) == 63) zn = zb[q + 4];
+        if (!live) return;
+        float4 o;
+        o.x = shade(Iv.x, z0.x, z0.y, z1.x, true, has_b);
+        o.y = shade(Iv.y, z0.y, z0.z, z1.y, true, has_b);
+        o.z = shade(Iv.z, z0.z, z0.w, z1.z, true, has_b);
+        o.w = shade(Iv.w, z0.w, zn, z1.w, has_r, has_b);
+        st_at(reinterpret_cast<float4*>(ob), q >> 2, o);
+    } else {
+        const unsigned p = blockIdx.x * NT + threadIdx.x;
+        if (p >= HW) return;
+        const unsigned y = p / (unsigned)W, x = p - y * (unsigned)W;
+        const bool has_r = x + 1 < (unsigned)W, has_b = y + 1 < (unsigned)H;
+        const float z0 = zb[p];
+        ob[p] = shade(Ib[p], z0, has_r ? zb[p + 1] : z0, has_b ? zb[p + W] : z0, has_r, has_b);
+    }
 }
 
 // Scene point of pixel p at depth z: (z * ray_x[x], z * ray_y[y], z * 1, 1), the products rounded
@@ -82,10 +115,14 @@ __global__ __launch_bounds__(NT) void capture_project_kernel(const float* __rest
 // Inverse warp: camera pixel -> projector pixel; samples the coded pattern and the projector-frame
 // scene coordinates (ray_x, ray_y, z_p) with the same four taps and composites both with the
 // visibility mask.
-template <bool FMA>
+// LDSRAY: the two ray tables (W + H floats) are staged in LDS first, which turns six of the fifteen
+// per-pixel gathers into LDS reads; used while the tables are small enough not to cost occupancy.
+constexpr int RAY_LDS_MAX = 4096;         // floats
+
+template <bool FMA, bool LDSRAY>
 __global__ __launch_bounds__(NT) void capture_sample_kernel(const float* __restrict__ z_c,
-                                                            const float* __restrict__ ray_x,
-                                                            const float* __restrict__ ray_y,
+                                                            const float* __restrict__ ray_x_g,
+                                                            const float* __restrict__ ray_y_g,
                                                             const float* __restrict__ Tm, const float* __restrict__ Ip,
                                                             const float* __restrict__ z_p,
                                                             const uint8_t* __restrict__ mask_u8, int H, int W,
@@ -107,6 +144,15 @@ __global__ __launch_bounds__(NT) void capture_sample_kernel(const float* __restr
             z[i] = zb[p];
             mv[i] = (float)mk[p];
         }
+    }
+    extern __shared__ float ray_lds[];    // [W] ray_x, then [H] ray_y
+    const float* ray_x = ray_x_g;
+    const float* ray_y = ray_y_g;
+    if (LDSRAY) {
+        for (int i = threadIdx.x; i < W + H; i += NT) ray_lds[i] = i < W ? ray_x_g[i] : ray_y_g[i - W];
+        __syncthreads();
+        ray_x = ray_lds;
+        ray_y = ray_lds + W;
     }
     float gx[PPL], gy[PPL], i00[PPL], i01[PPL], i10[PPL], i11[PPL], z00[PPL], z01[PPL], z10[PPL], z11[PPL];
     float rx0[PPL], rx1[PPL], ry0[PPL], ry1[PPL];
@@ -262,8 +308,13 @@ extern "C" int fc3d_reflectance_fwd(void* stream, const float* I, int64_t i_sb, 
                                     float* out) {
     if (!I || !z || !out || i_sb < 0) return FC3D_EINVAL;
     if (int e = check_img(B, H, W)) return e;
-    FC3D_LAUNCH("reflectance", reflectance_kernel, dim3(cdiv((long)H * W, NT), B), dim3(NT), 0, (hipStream_t)stream, I,
-                (long)i_sb, z, H, W, out);
+    const long HW = (long)H * W;
+    if (W % 4 == 0 && i_sb % 4 == 0 && aligned16(I) && aligned16(z) && aligned16(out))
+        FC3D_LAUNCH("reflectance", reflectance_kernel<4>, dim3(cdiv(HW, NT * 4), B), dim3(NT), 0, (hipStream_t)stream, I,
+                    (long)i_sb, z, H, W, out);
+    else
+        FC3D_LAUNCH("reflectance", reflectance_kernel<1>, dim3(cdiv(HW, NT), B), dim3(NT), 0, (hipStream_t)stream, I,
+                    (long)i_sb, z, H, W, out);
     return FC3D_OK;
 }
 
@@ -280,17 +331,25 @@ extern "C" int fc3d_capture_warp_fwd(void* stream, const float* Ip, const float*
     if (!mask_is_clear) {
         if (int e = zero_fill(s, mask_u8, (size_t)B * H * W)) return e;
     }
+    const bool lds = W + H <= RAY_LDS_MAX;
+    const size_t nlds = lds ? (size_t)(W + H) * sizeof(float) : 0;
+#define SAMPLE_ARGS z_c, ray_x, ray_y, T_c2p, Ip, z_p, (const uint8_t*)mask_u8, H, W, grid_c2p, Ic_masked, xyz_cview
+#define SAMPLE_LAUNCH(FMA)                                                                                     \
+    do {                                                                                                       \
+        if (lds) FC3D_LAUNCH("capture_sample", (capture_sample_kernel<FMA, true>), g, blk, nlds, s, SAMPLE_ARGS); \
+        else FC3D_LAUNCH("capture_sample", (capture_sample_kernel<FMA, false>), g, blk, 0, s, SAMPLE_ARGS);    \
+    } while (0)
     if (use_fma(H, W)) {
         FC3D_LAUNCH("capture_project_splat", capture_project_kernel<true>, g, blk, 0, s, z_p, ray_x, ray_y, T_p2c, H, W,
                     grid_p2c, mask_u8);
-        FC3D_LAUNCH("capture_sample", capture_sample_kernel<true>, g, blk, 0, s, z_c, ray_x, ray_y, T_c2p, Ip, z_p,
-                    (const uint8_t*)mask_u8, H, W, grid_c2p, Ic_masked, xyz_cview);
+        SAMPLE_LAUNCH(true);
     } else {
         FC3D_LAUNCH("capture_project_splat", capture_project_kernel<false>, g, blk, 0, s, z_p, ray_x, ray_y, T_p2c, H, W,
                     grid_p2c, mask_u8);
-        FC3D_LAUNCH("capture_sample", capture_sample_kernel<false>, g, blk, 0, s, z_c, ray_x, ray_y, T_c2p, Ip, z_p,
-                    (const uint8_t*)mask_u8, H, W, grid_c2p, Ic_masked, xyz_cview);
+        SAMPLE_LAUNCH(false);
     }
+#undef SAMPLE_LAUNCH
+#undef SAMPLE_ARGS
     return FC3D_OK;
 }
 

@@ -84,7 +84,7 @@ def test_forward_model_and_reproj_vs_oracle(env, monkeypatch, fused):
     assert rel_err(zhat.grad.cpu().numpy(), zh.grad.numpy()) < 2e-3      # L1 loss: sign flips at |diff|~0 pixels
 
 
-@pytest.mark.parametrize("B,H,W", [(2, 96, 128), (3, 37, 53), (1, 4, 5), (1, 1, 1)])
+@pytest.mark.parametrize("B,H,W", [(2, 96, 128), (3, 37, 53), (1, 4, 5), (1, 1, 1), (1, 8, 4100)])
 def test_capture_kernels_match_composed_operators(env, monkeypatch, B, H, W):
     """The capture kernels against the operators they stand for, on the same device inputs:
     warp straight from the depth maps == points + warp_p2c + bilinear_sampler (bit for bit, masks
