@@ -72,6 +72,25 @@ def main():
     torch.cuda.synchronize()
     prof = profiler.report()
     profiler.enable(False)
+    # the box filters that follow the capture in the training step, against avg_pool2d
+    import torch.nn.functional as F
+    img, msk = step(True)[0], step(True)[1]
+
+    def timed(fn, n=20):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return 1e6 * (time.perf_counter() - t0) / n
+
+    pool = lambda t, k: F.avg_pool2d(t.permute(0, 3, 1, 2), k, stride=1, padding=k // 2).permute(0, 2, 3, 1)  # noqa: E731
+    box = {"local_norm17_us": timed(lambda: capture.local_norm(img, 17, 0.01)),
+           "local_norm17_torch_us": timed(lambda: img / (pool(img, 17) + 0.01)),
+           "erode5_us": timed(lambda: capture.erode(msk, 5)),
+           "erode5_torch_us": timed(lambda: (pool(msk, 5) > 0.999).float())}
     px = B * H * W
     kern = {k: round(1e3 * ms / n, 2) for k, (n, ms) in prof.items()}
     kus = sum(1e3 * ms / n for k, (n, ms) in prof.items())
@@ -85,7 +104,7 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "all kernels of one capture", "achieved": ALG_BYTES * px / (kus * 1e-6) / 1e9,
                      "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ALG_BYTES * px / (kus * 1e-6) / HBM_PEAK,
                      "traffic": None, "kernel_us": kus},
-        "kernels_us": kern}), flush=True)
+        "kernels_us": kern, "box_filters": {k: round(v, 1) for k, v in box.items()}}), flush=True)
 
 
 if __name__ == "__main__":

@@ -54,8 +54,17 @@ def with_reflectance(I, depth):
     return I * (torch.cos(theta) * 0.8 + 0.2)
 
 
+def _native_box(t, k):
+    """The box-filter kernel serves one-channel GPU images that carry no gradient."""
+    return (t.is_cuda and t.dim() == 4 and t.shape[3] == 1 and t.shape[0] > 0 and k % 2 == 1 and k <= 33
+            and t.dtype == torch.float32 and not (torch.is_grad_enabled() and t.requires_grad))
+
+
 def local_norm(Im, kernelsize=17, constant=0.01):
     """Im / (box mean + c); utils_pytorch.py:285-301."""
+    if _native_box(Im, kernelsize):
+        from . import ops
+        return ops.box_filter(Im, kernelsize, "local_norm", constant)
     mean = F.avg_pool2d(Im.permute(0, 3, 1, 2), kernelsize, stride=1, padding=kernelsize // 2).permute(0, 2, 3, 1)
     return Im / (mean + constant)
 
@@ -70,6 +79,9 @@ def cost_L1_mask(GT, hat, mask):
 
 def erode(mask, k):
     """1 where the whole k x k neighbourhood is 1 (avg-pool > 0.999); train_pytorch.py:184-186."""
+    if _native_box(mask, k):
+        from . import ops
+        return ops.box_filter(mask, k, "erode")
     m = F.avg_pool2d(mask.permute(0, 3, 1, 2), kernel_size=k, stride=1, padding=k // 2).permute(0, 2, 3, 1)
     return (m > 0.999).float()
 

@@ -300,9 +300,99 @@ __global__ __launch_bounds__(NT) void capture_sensor_kernel(const float* __restr
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// k x k box mean with zero padding (avg_pool2d, stride 1, padding k/2, padded cells counted) and
+// the two things the training loop does with it: local normalisation of the capture that feeds
+// the networks, and erosion of a 0/1 mask
+// ---------------------------------------------------------------------------------------
+constexpr int BOX_TW = 64, BOX_TH = 32, BOX_MAX_K = 33;
+enum BoxMode { kBoxMean = 0, kBoxLocalNorm = 1, kBoxErode = 2 };
+
+// One 64 x 32 output tile per workgroup: the tile and its halo go to LDS once (zeros outside the
+// image).  Row sums over k columns are formed into a second LDS array by lanes that each walk 16
+// pixels of one row with a running sum (add the entering value, subtract the leaving one; lanes sit
+// on different rows and the row pitch is odd, so the reads spread over the banks), then every
+// lane walks 8 rows down its column the same way.  Sums of a 0/1 mask are exact, so the erosion
+// is bit-exact; the mean differs from a row-major window sum by rounding only (the running sums
+// restart every 16 columns / 8 rows).
+constexpr int BOX_SEG = 16;               // pixels a lane walks in the row pass
+
+__host__ __device__ inline int box_pitch(int n) { return n | 1; }
+
+template <int MODE>
+__global__ __launch_bounds__(NT) void box_kernel(const float* __restrict__ in, int H, int W, int r, float c,
+                                                 float* __restrict__ out) {
+    extern __shared__ float box_lds[];
+    const int k = 2 * r + 1;
+    const int LW = BOX_TW + 2 * r, LH = BOX_TH + 2 * r;
+    const int TP = box_pitch(LW), HP = box_pitch(BOX_TW);
+    float* tile = box_lds;                 // [LH][TP]
+    float* hs = box_lds + LH * TP;         // [LH][HP]
+    const int b = blockIdx.z;
+    const int x0 = blockIdx.x * BOX_TW, y0 = blockIdx.y * BOX_TH;
+    const float* img = in + (long)b * H * W;
+    for (int ty = threadIdx.x >> 6; ty < LH; ty += NT / 64) {
+        const int gy = y0 - r + ty;
+        const bool rowok = gy >= 0 && gy < H;
+        for (int tx = threadIdx.x & 63; tx < LW; tx += 64) {
+            const int gx = x0 - r + tx;
+            tile[ty * TP + tx] = (rowok && gx >= 0 && gx < W) ? img[(long)gy * W + gx] : 0.0f;
+        }
+    }
+    __syncthreads();
+    for (int job = threadIdx.x; job < LH * (BOX_TW / BOX_SEG); job += NT) {
+        const int ty = job % LH, seg = job / LH;           // neighbouring lanes: neighbouring rows
+        const float* row = tile + ty * TP + seg * BOX_SEG;
+        float* dst = hs + ty * HP + seg * BOX_SEG;
+        float a = 0.0f;
+        for (int d = 0; d < k; ++d) a += row[d];
+        dst[0] = a;
+        for (int i = 1; i < BOX_SEG; ++i) {
+            a = (a + row[i + k - 1]) - row[i - 1];
+            dst[i] = a;
+        }
+    }
+    __syncthreads();
+    const int x = threadIdx.x & 63;
+    const int gx = x0 + x;
+    if (gx >= W) return;
+    const float area = (float)(k * k);
+    float* o = out + (long)b * H * W;
+    constexpr int ROWS = BOX_TH / (NT / 64);
+    const int ty0 = (threadIdx.x >> 6) * ROWS;
+    const float* col = hs + ty0 * HP + x;
+    float a = 0.0f;
+    for (int d = 0; d < k; ++d) a += col[d * HP];
+    for (int j = 0; j < ROWS; ++j) {
+        const int gy = y0 + ty0 + j;
+        if (gy >= H) break;
+        if (j > 0) a = (a + col[(j + k - 1) * HP]) - col[(j - 1) * HP];
+        const float mean = a / area;
+        float v;
+        if (MODE == kBoxMean) v = mean;
+        else if (MODE == kBoxLocalNorm) v = tile[(ty0 + j + r) * TP + x + r] / (mean + c);
+        else v = mean > 0.999f ? 1.0f : 0.0f;
+        o[(long)gy * W + gx] = v;
+    }
+}
+
 }  // namespace fc3d
 
 using namespace fc3d;
+
+extern "C" int fc3d_box_filter(void* stream, const float* in, int B, int H, int W, int k, int mode, float c,
+                               float* out) {
+    if (!in || !out || in == out || k < 1 || k > BOX_MAX_K || (k & 1) == 0 || mode < 0 || mode > 2) return FC3D_EINVAL;
+    if (int e = check_img(B, H, W)) return e;
+    const int r = k / 2;
+    const size_t lds = (size_t)(BOX_TH + 2 * r) * (box_pitch(BOX_TW + 2 * r) + box_pitch(BOX_TW)) * sizeof(float);
+    const dim3 g(cdiv(W, BOX_TW), cdiv(H, BOX_TH), B), blk(NT);
+    hipStream_t s = (hipStream_t)stream;
+    if (mode == kBoxMean) FC3D_LAUNCH("box_mean", box_kernel<kBoxMean>, g, blk, lds, s, in, H, W, r, c, out);
+    else if (mode == kBoxLocalNorm) FC3D_LAUNCH("box_local_norm", box_kernel<kBoxLocalNorm>, g, blk, lds, s, in, H, W, r, c, out);
+    else FC3D_LAUNCH("box_erode", box_kernel<kBoxErode>, g, blk, lds, s, in, H, W, r, c, out);
+    return FC3D_OK;
+}
 
 extern "C" int fc3d_reflectance_fwd(void* stream, const float* I, int64_t i_sb, const float* z, int B, int H, int W,
                                     float* out) {

@@ -514,3 +514,19 @@ def capture_post(Ic, offset, gauss, scale, mask_u8):
                                       _dense(scale).data_ptr(), _dense(mask_u8).data_ptr(), B, H, W,
                                       scaled.data_ptr(), valid.data_ptr(), ws.data_ptr()), "fc3d_capture_post")
     return scaled, valid
+
+
+def box_filter(img: torch.Tensor, k: int, mode: str = "mean", c: float = 0.0) -> torch.Tensor:
+    """k x k zero-padded box mean of a one-channel [B,H,W,1] image ("mean"), the image divided by
+    (mean + c) ("local_norm"), or the erosion mean > 0.999 of a 0/1 mask ("erode"); no gradient."""
+    dev = _need_gpu(img)
+    if img.dim() != 4 or img.shape[3] != 1:
+        raise ValueError(f"expected a [B,H,W,1] image, got {tuple(img.shape)}")
+    m = {"mean": 0, "local_norm": 1, "erode": 2}[mode]
+    B, H, W = img.shape[0], img.shape[1], img.shape[2]
+    src = _dense(img.detach())
+    out = torch.empty((B, H, W, 1), dtype=torch.float32, device=dev)
+    with _on_device(dev):
+        _check(_lib.fc3d_box_filter(_stream(), src.data_ptr(), B, H, W, int(k), m, float(c), out.data_ptr()),
+               "fc3d_box_filter")
+    return out

@@ -231,6 +231,17 @@ size_t fc3d_capture_post_workspace(int B, int H, int W);
 int fc3d_capture_post(void *stream, const float *Ic, const float *offset, const float *gauss, const float *scale,
                       const uint8_t *mask_u8, int B, int H, int W, float *Ic_scaled, float *Ic_mask, void *workspace);
 
+/* k x k box mean with zero padding, F.avg_pool2d(x, k, stride=1, padding=k/2) on one-channel
+ * images [B][H][W] (k odd, <= 33), and its two uses in the training loop:
+ *   mode 0  out = mean
+ *   mode 1  out = in / (mean + c)       ln, utils_pytorch.py:285-301 (k 17, c 0.01)
+ *   mode 2  out = mean > 0.999 ? 1 : 0  mask erosion, train_pytorch.py:184-186, :222-224 (k 5),
+ *                                       utils_pytorch.py:193-194 (k 9); bit-exact for 0/1 masks
+ * The mean is a floating-point result (row sums, then a column sum: rounding-level difference
+ * from a row-major window sum).  in and out must not alias.  No gradient: the reference applies
+ * these to the simulated capture and to masks only.                                          */
+int fc3d_box_filter(void *stream, const float *in, int B, int H, int W, int k, int mode, float c, float *out);
+
 /* ------------------------------------------------------------------------ */
 /* optional per-kernel timing (no counterpart in the reference, which has no   */
 /* profiling hooks): while enabled every kernel launch of this library is       */

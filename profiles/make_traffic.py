@@ -34,6 +34,10 @@ NAMES = (
     ("warp_sample_kernel", "warp_sample"), ("bilinear_bwd_img_scatter_kernel", "bilinear_bwd_img_scatter"),
     ("bilinear_bwd_img_merge_kernel", "bilinear_bwd_img_merge"),
     ("bilinear_bwd_img_overflow_kernel", "bilinear_bwd_img_overflow"), ("points_fwd_kernel", "points_fwd"),
+    ("code_pattern_fwd_sweep_kernel", "code_pattern_fwd"), ("code_pattern_bwd_sweep_kernel", "code_pattern_bwd"),
+    ("zero_fill_kernel", "zero_fill"), ("reflectance_kernel", "reflectance"),
+    ("capture_project_kernel", "capture_project_splat"), ("capture_sample_kernel", "capture_sample"),
+    ("capture_peak_kernel", "capture_peak"), ("capture_sensor_kernel", "capture_sensor"),
 )
 
 

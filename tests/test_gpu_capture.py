@@ -136,6 +136,31 @@ def test_capture_kernels_match_composed_operators(env, monkeypatch, B, H, W):
     assert torch.equal(valid.cpu(), Im)
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 37, 53), (1, 64, 128), (3, 5, 3), (1, 100, 70)])
+def test_box_filter_vs_avg_pool(env, B, H, W):
+    """Local normalisation and mask erosion against F.avg_pool2d on the CPU: erosion of a 0/1
+    mask bit for bit, means within rounding."""
+    from fc3d import ops
+    capture = env["capture"]
+    rs = np.random.RandomState(B * 1000 + H)
+    img = torch.from_numpy(rs.uniform(0, 1, (B, H, W, 1)).astype(np.float32))
+    mask = torch.from_numpy((rs.uniform(0, 1, (B, H, W, 1)) > 0.08).astype(np.float32))
+    pool = lambda t, k: F.avg_pool2d(t.permute(0, 3, 1, 2), k, stride=1, padding=k // 2).permute(0, 2, 3, 1)  # noqa: E731
+    for k in (1, 3, 5, 9, 17, 33):
+        mean = ops.box_filter(img.cuda(), k, "mean").cpu()
+        assert rel_err(mean.numpy(), pool(img, k).numpy()) < 1e-5
+        ln = capture.local_norm(img.cuda(), k, 0.01).cpu()
+        assert rel_err(ln.numpy(), (img / (pool(img, k) + 0.01)).numpy()) < 1e-5
+        er = capture.erode(mask.cuda(), k).cpu()
+        assert torch.equal(er, (pool(mask, k) > 0.999).float())
+    # a cropped (strided) view, as the training step passes
+    v = img.cuda()[:, 1:H - 1, 1:W - 1, :]
+    if v.numel():
+        assert rel_err(capture.local_norm(v, 5).cpu().numpy(), (v.cpu() / (pool(v.cpu(), 5) + 0.01)).numpy()) < 1e-5
+    with pytest.raises(RuntimeError):
+        ops.box_filter(img.cuda(), 4, "mean")
+
+
 def test_train_step_runs(env, monkeypatch):
     G, O, capture, synth = env["G"], env["O"], env["capture"], env["synth"]
     B, H, W = 2, 64, 64
