@@ -70,6 +70,32 @@ def main():
             step(fused)
         torch.cuda.synchronize()
         out[name] = (time.perf_counter() - t0) / a.steps
+    # the whole loss (erosion, chain, masked sums, backward to the predicted depth): loss kernels
+    # against the chain kernels + tensor reductions, and against the fully composed form
+    Ic_cap = d(rs.uniform(0, 1, (B, H, W, 1)).astype(np.float32))
+    zc_gt = d(sc["z_c"])
+    mask = d((rs.uniform(0, 1, (B, H, W, 1)) > 0.02).astype(np.float32))
+
+    def loss_step(mode):
+        zp.grad = None
+        if mode == "kernels":
+            vals = capture.reProj_IpGT(zp, pose, xy, Ic_cap, zc_gt, mask, img, fused=True)
+        else:
+            me = capture.erode(mask, 5)
+            zc, Ir = capture.reproject(zp * me, pose, xy, img, fused=(mode == "chain"))
+            vals = (capture.cost_L1_mask(Ic_cap, Ir, me) + capture.cost_rms_mask(zc_gt, zc, me),)
+        vals[0].backward()
+
+    loss_t = {}
+    for mode in ("kernels", "chain", "composed"):
+        for _ in range(a.warmup):
+            loss_step(mode)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            loss_step(mode)
+        torch.cuda.synchronize()
+        loss_t[mode] = (time.perf_counter() - t0) / a.steps
     profiler.enable(True)
     profiler.report()
     for _ in range(a.steps):
@@ -90,7 +116,9 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "reproject_fwd + reproject_bwd", "achieved": ALG_BYTES * px / (kus * 1e-6) / 1e9,
                      "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ALG_BYTES * px / (kus * 1e-6) / HBM_PEAK,
                      "traffic": None, "kernel_us": kus},
-        "kernels_us": kern}), flush=True)
+        "kernels_us": kern,
+        "loss_ms_per_step": {"loss_kernels": 1e3 * loss_t["kernels"], "chain_kernels_plus_tensor_reductions": 1e3 * loss_t["chain"],
+                             "composed": 1e3 * loss_t["composed"]}}), flush=True)
 
 
 if __name__ == "__main__":

@@ -166,8 +166,18 @@ def reproject(zp, pose_p2c, xy, IpGT, fused=True):
 
 
 def reProj_IpGT(zp_cView, pose_p2c, xy, Ic, zcGT, maskC, IpGT, fused=True):
-    """Re-projection loss; train_pytorch.py:179-211 (one crop per sample)."""
+    """Re-projection loss; train_pytorch.py:179-211 (one crop per sample).  fused=True: erosion,
+    chain, masked sums and the scalar arithmetic of the losses run in the loss kernels (gradient
+    w.r.t. zp_cView only)."""
     me = erode(maskC, 5)
+    grads_elsewhere = torch.is_grad_enabled() and any(
+        t.requires_grad for t in (pose_p2c, xy, Ic, zcGT, maskC, IpGT))
+    if fused and zp_cView.is_cuda and zp_cView.shape[0] > 0 and not grads_elsewhere:
+        from . import ops
+        K = G._intrinsics_for(zp_cView.shape[0], zp_cView.device)
+        _, T_c2p, pose_c2p = ops.pose_transforms(pose_p2c.detach(), K, want_inv=True, want_a=True)
+        L = ops.ReprojLossFn.apply(zp_cView, me, xy, pose_c2p, T_c2p, IpGT, Ic, zcGT)
+        return L[0], L[1], L[2], L[3]
     zp = zp_cView * me
     zc, Ic_reProj = reproject(zp, pose_p2c, xy, IpGT, fused)
     loss_zc_rms = cost_rms_mask(zcGT, zc, me)

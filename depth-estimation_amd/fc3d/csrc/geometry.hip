@@ -743,6 +743,153 @@ __global__ __launch_bounds__(NT) void reproject_bwd_kernel(const float* __restri
     st_at(g_zp + base, p, gz / zc_den(a, r.x, r.y));
 }
 
+// ---------------------------------------------------------------------------------------
+// The re-projection loss of reProj_IpGT (train_pytorch.py:188-207) on top of the chain above: the
+// predicted depth is masked, re-projected and compared with the capture and the true camera depth,
+// and only four sums leave the kernel,
+//   S0 = sum (m (zcGT - zc))^2   S1 = sum (m (Ic - Ic'))^2   S2 = sum m |Ic - Ic'|   S3 = sum m
+// (m = the eroded mask, Ic' = the re-projected pattern): neither zc nor Ic' is ever stored.  One
+// partial per workgroup, added in a fixed order by a second launch, so the sums are reproducible.
+// The backward pass recomputes the chain (it needs the taps anyway) and turns the gradients of the
+// three sums straight into the gradient of the predicted depth.
+// ---------------------------------------------------------------------------------------
+struct ReprojPx {
+    float me, zc, zden, xu, yu, den, icr, ic, zgt;
+    Taps t;
+    float i00, i01, i10, i11;
+};
+
+template <bool FMA>
+__device__ __forceinline__ ReprojPx reproj_px(const float* __restrict__ zhat, const float* __restrict__ mask,
+                                              const float* __restrict__ xy, const float* a, const float* T,
+                                              const float* __restrict__ im, const float* __restrict__ Ic,
+                                              const float* __restrict__ zcGT, long base, unsigned p, int Hs, int Ws) {
+    ReprojPx q;
+    const float2 r = ld_at(reinterpret_cast<const float2*>(xy) + base, p);
+    q.me = ld_at(mask + base, p);
+    q.ic = ld_at(Ic + base, p);
+    q.zgt = ld_at(zcGT + base, p);
+    const float zp = __fmul_rn(ld_at(zhat + base, p), q.me);
+    q.zden = zc_den(a, r.x, r.y);
+    q.zc = __fsub_rn(zp, a[11]) / q.zden;
+    const float c0 = __fmul_rn(q.zc, r.x), c1 = __fmul_rn(q.zc, r.y), c2 = __fmul_rn(q.zc, 1.0f);
+    q.xu = row_dot<FMA>(T + 0, c0, c1, c2, 1.0f);
+    q.yu = row_dot<FMA>(T + 4, c0, c1, c2, 1.0f);
+    q.den = __fadd_rn(row_dot<FMA>(T + 8, c0, c1, c2, 1.0f), 1e-10f);
+    q.t = make_taps(q.xu / q.den, q.yu / q.den, Hs, Ws);
+    q.i00 = ld_at(im, (unsigned)(q.t.y0 * Ws + q.t.x0)); q.i01 = ld_at(im, (unsigned)(q.t.y1 * Ws + q.t.x0));
+    q.i10 = ld_at(im, (unsigned)(q.t.y0 * Ws + q.t.x1)); q.i11 = ld_at(im, (unsigned)(q.t.y1 * Ws + q.t.x1));
+    q.icr = blend(q.t, q.i00, q.i01, q.i10, q.i11);
+    return q;
+}
+
+template <bool FMA>
+__global__ __launch_bounds__(NT) void reproj_loss_fwd_kernel(const float* __restrict__ zhat, const float* __restrict__ mask,
+                                                             const float* __restrict__ xy, const float* __restrict__ inv,
+                                                             const float* __restrict__ Tm, const float* __restrict__ img,
+                                                             const float* __restrict__ Ic, const float* __restrict__ zcGT,
+                                                             int H, int W, int Hs, int Ws, float4* __restrict__ partial) {
+    __shared__ float4 sh[NT / 64];
+    const int b = blockIdx.y;
+    const unsigned HW = (unsigned)(H * W);
+    const unsigned p = blockIdx.x * NT + threadIdx.x;
+    float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (p < HW) {
+        const ReprojPx q = reproj_px<FMA>(zhat, mask, xy, inv + (long)b * 16, Tm + (long)b * 16,
+                                          img + (long)b * Hs * Ws, Ic, zcGT, (long)b * HW, p, Hs, Ws);
+        const float dz = __fmul_rn(q.me, __fsub_rn(q.zgt, q.zc));
+        const float di = __fsub_rn(q.ic, q.icr);
+        const float mi = __fmul_rn(q.me, di);
+        s = make_float4(__fmul_rn(dz, dz), __fmul_rn(mi, mi), __fmul_rn(q.me, fabsf(di)), q.me);
+    }
+    s.x = wave_sum(s.x); s.y = wave_sum(s.y); s.z = wave_sum(s.z); s.w = wave_sum(s.w);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float4 t = sh[0];
+#pragma unroll
+        for (int w = 1; w < NT / 64; ++w) { t.x += sh[w].x; t.y += sh[w].y; t.z += sh[w].z; t.w += sh[w].w; }
+        partial[(long)b * gridDim.x + blockIdx.x] = t;
+    }
+}
+
+// sums[0..3] = the partials added in index order (double accumulators, one workgroup), and the
+// losses made of them with the reference's fp32 expressions (utils_pytorch.py:161-163, :177;
+// train_pytorch.py:209): losses = [L1 + zc_rms, zc_rms, Ic_rms, L1],
+//   rms = sqrt(S / max(n, 1e-6) + 1e-6),  L1 = S2 / (n + 1).
+__global__ __launch_bounds__(NT) void reproj_loss_sum_kernel(const float4* __restrict__ partial, long n,
+                                                             float* __restrict__ sums, float* __restrict__ losses) {
+    __shared__ double sh[NT][4];
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+    for (long i = threadIdx.x; i < n; i += NT) {
+        const float4 v = partial[i];
+        a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sh[threadIdx.x][j] = a[j];
+    __syncthreads();
+    for (int o = NT / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sh[threadIdx.x][j] += sh[threadIdx.x + o][j];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) sums[threadIdx.x] = (float)sh[0][threadIdx.x];
+    if (threadIdx.x == 0) {
+        const float S0 = (float)sh[0][0], S1 = (float)sh[0][1], S2 = (float)sh[0][2], cnt = (float)sh[0][3];
+        const float nc = fmaxf(cnt, 1e-6f);
+        const float zc_rms = sqrtf(__fadd_rn(S0 / nc, 1e-6f));
+        const float ic_rms = sqrtf(__fadd_rn(S1 / nc, 1e-6f));
+        const float l1 = S2 / __fadd_rn(cnt, 1.0f);
+        losses[0] = __fadd_rn(l1, zc_rms);
+        losses[1] = zc_rms;
+        losses[2] = ic_rms;
+        losses[3] = l1;
+    }
+}
+
+template <bool FMA>
+__global__ __launch_bounds__(NT) void reproj_loss_bwd_kernel(const float* __restrict__ g_losses, const float* __restrict__ sums,
+                                                             const float* __restrict__ zhat,
+                                                             const float* __restrict__ mask, const float* __restrict__ xy,
+                                                             const float* __restrict__ inv, const float* __restrict__ Tm,
+                                                             const float* __restrict__ img, const float* __restrict__ Ic,
+                                                             const float* __restrict__ zcGT, int H, int W, int Hs, int Ws,
+                                                             float* __restrict__ g_zhat) {
+    const int b = blockIdx.y;
+    const unsigned HW = (unsigned)(H * W);
+    const unsigned p = blockIdx.x * NT + threadIdx.x;
+    if (p >= HW) return;
+    const long base = (long)b * HW;
+    const float* T = Tm + (long)b * 16;
+    // gradients of the three sums from those of the four losses:
+    //   d rms / d S = 1 / (2 rms max(n, 1e-6)),  d L1 / d S2 = 1 / (n + 1)
+    const float nc = fmaxf(sums[3], 1e-6f);
+    const float zc_rms = sqrtf(sums[0] / nc + 1e-6f), ic_rms = sqrtf(sums[1] / nc + 1e-6f);
+    const float g0 = (g_losses[0] + g_losses[1]) / (2.0f * zc_rms * nc);
+    const float g1 = g_losses[2] / (2.0f * ic_rms * nc);
+    const float g2 = (g_losses[0] + g_losses[3]) / (sums[3] + 1.0f);
+    const ReprojPx q = reproj_px<FMA>(zhat, mask, xy, inv + (long)b * 16, T, img + (long)b * Hs * Ws, Ic, zcGT, base, p,
+                                      Hs, Ws);
+    // d S0 / d zc = -2 m^2 (zcGT - zc);  d S1 / d Ic' = -2 m^2 (Ic - Ic');  d S2 / d Ic' = -m sign(Ic - Ic')
+    const float m2 = q.me * q.me;
+    const float di = q.ic - q.icr;
+    const float sgn = di > 0.0f ? 1.0f : (di < 0.0f ? -1.0f : 0.0f);
+    float gz = -2.0f * g0 * m2 * (q.zgt - q.zc);
+    const float go = -2.0f * g1 * m2 * di - g2 * q.me * sgn;
+    const float2 r = ld_at(reinterpret_cast<const float2*>(xy) + base, p);
+    const float ggx = go * (q.t.wy0 * (q.i10 - q.i00) + q.t.wy1 * (q.i11 - q.i01));   // as reproject_bwd
+    const float ggy = go * (q.t.wx0 * (q.i01 - q.i00) + q.t.wx1 * (q.i11 - q.i10));
+    const float gxu = ggx / q.den, gyu = ggy / q.den;
+    const float gzu = -(ggx * q.xu + ggy * q.yu) / (q.den * q.den);
+    const float gc0 = T[0] * gxu + T[4] * gyu + T[8] * gzu;
+    const float gc1 = T[1] * gxu + T[5] * gyu + T[9] * gzu;
+    const float gc2 = T[2] * gxu + T[6] * gyu + T[10] * gzu;
+    gz += (gc0 * r.x + gc1 * r.y) + gc2;
+    st_at(g_zhat + base, p, (gz / q.zden) * q.me);
+}
+
 // Backward of coord_transform w.r.t. coord: with den = zu + 1e-10,
 //   g_xu = g_x/den, g_yu = g_y/den, g_zu = -(g_x*xu + g_y*yu)/den^2, g_coord = T^T g_u.
 template <int LAYOUT, bool FMA>
@@ -1066,6 +1213,42 @@ extern "C" int fc3d_reproject_bwd(void* stream, const float* g_zc, const float* 
     hipStream_t s = (hipStream_t)stream;
     if (use_fma(H, W)) FC3D_LAUNCH("reproject_bwd", reproject_bwd_kernel<true>, g, blk, 0, s, g_zc, g_out, zc, xy, inv, T, img, H, W, Hs, Ws, g_zp);
     else FC3D_LAUNCH("reproject_bwd", reproject_bwd_kernel<false>, g, blk, 0, s, g_zc, g_out, zc, xy, inv, T, img, H, W, Hs, Ws, g_zp);
+    return FC3D_OK;
+}
+
+extern "C" size_t fc3d_reproj_loss_workspace(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)B * cdiv((long)H * W, NT) * sizeof(float4);
+}
+
+extern "C" int fc3d_reproj_loss_fwd(void* stream, const float* zp_hat, const float* mask, const float* xy,
+                                    const float* inv, const float* T, const float* img, const float* Ic,
+                                    const float* zcGT, int B, int H, int W, int Hs, int Ws, void* workspace,
+                                    float* sums, float* losses) {
+    if (!zp_hat || !mask || !xy || !inv || !T || !img || !Ic || !zcGT || !workspace || !sums || !losses)
+        return FC3D_EINVAL;
+    if (int e = check_reproject(xy, B, H, W, Hs, Ws)) return e;
+    if (!aligned16(workspace)) return FC3D_EALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 g(cdiv((long)H * W, NT), B), blk(NT);
+    float4* partial = (float4*)workspace;
+    if (use_fma(H, W)) FC3D_LAUNCH("reproj_loss_fwd", reproj_loss_fwd_kernel<true>, g, blk, 0, s, zp_hat, mask, xy, inv, T, img, Ic, zcGT, H, W, Hs, Ws, partial);
+    else FC3D_LAUNCH("reproj_loss_fwd", reproj_loss_fwd_kernel<false>, g, blk, 0, s, zp_hat, mask, xy, inv, T, img, Ic, zcGT, H, W, Hs, Ws, partial);
+    FC3D_LAUNCH("reproj_loss_sum", reproj_loss_sum_kernel, dim3(1), blk, 0, s, (const float4*)partial, (long)g.x * B, sums, losses);
+    return FC3D_OK;
+}
+
+extern "C" int fc3d_reproj_loss_bwd(void* stream, const float* g_losses, const float* sums, const float* zp_hat,
+                                    const float* mask,
+                                    const float* xy, const float* inv, const float* T, const float* img,
+                                    const float* Ic, const float* zcGT, int B, int H, int W, int Hs, int Ws,
+                                    float* g_zp_hat) {
+    if (!g_losses || !sums || !zp_hat || !mask || !xy || !inv || !T || !img || !Ic || !zcGT || !g_zp_hat) return FC3D_EINVAL;
+    if (int e = check_reproject(xy, B, H, W, Hs, Ws)) return e;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 g(cdiv((long)H * W, NT), B), blk(NT);
+    if (use_fma(H, W)) FC3D_LAUNCH("reproj_loss_bwd", reproj_loss_bwd_kernel<true>, g, blk, 0, s, g_losses, sums, zp_hat, mask, xy, inv, T, img, Ic, zcGT, H, W, Hs, Ws, g_zp_hat);
+    else FC3D_LAUNCH("reproj_loss_bwd", reproj_loss_bwd_kernel<false>, g, blk, 0, s, g_losses, sums, zp_hat, mask, xy, inv, T, img, Ic, zcGT, H, W, Hs, Ws, g_zp_hat);
     return FC3D_OK;
 }
 

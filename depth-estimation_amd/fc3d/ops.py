@@ -448,6 +448,52 @@ class ReprojectFn(torch.autograd.Function):
         return gp, None, None, None, None
 
 
+class ReprojLossFn(torch.autograd.Function):
+    """The re-projection loss (train_pytorch.py:188-211) from the predicted depth zp_hat and an
+    already eroded mask: a [4] tensor (loss_Ic_L1 + loss_zc_rms, loss_zc_rms, loss_Ic_rms,
+    loss_Ic_L1).  zc and the re-projected pattern never reach memory; gradient w.r.t. zp_hat only."""
+
+    @staticmethod
+    def forward(ctx, zp_hat, mask, xy, inv, T, img, Ic, zcGT):
+        dev = _need_gpu(zp_hat, mask, xy, inv, T, img, Ic, zcGT)
+        B, H, W, _ = zp_hat.shape
+        one = (B, H, W, 1)
+        if (tuple(zp_hat.shape) != one or tuple(mask.shape) != one or tuple(Ic.shape) != one
+                or tuple(zcGT.shape) != one or tuple(xy.shape) != (B, H, W, 2) or img.dim() != 4
+                or img.shape[0] != B or img.shape[3] != 1 or tuple(inv.shape) != (B, 4, 4)
+                or tuple(T.shape) != (B, 4, 4)):
+            raise RuntimeError(f"reproj_loss: zp_hat {tuple(zp_hat.shape)}, mask {tuple(mask.shape)}, xy "
+                               f"{tuple(xy.shape)}, Ic {tuple(Ic.shape)}, zcGT {tuple(zcGT.shape)}, img "
+                               f"{tuple(img.shape)}, inverse pose {tuple(inv.shape)}, transform {tuple(T.shape)}")
+        ts = tuple(_dense(t.detach()) for t in (zp_hat, mask, xy, inv, T, img, Ic, zcGT))
+        z, m, r, a, t, im, ic, zg = ts
+        sums = torch.empty(8, dtype=torch.float32, device=dev)       # [0:4] the masked sums, [4:8] the losses
+        ws = torch.empty(max(4, _lib.fc3d_reproj_loss_workspace(B, H, W) // 4), dtype=torch.float32, device=dev)
+        with _on_device(dev):
+            _check(_lib.fc3d_reproj_loss_fwd(_stream(), z.data_ptr(), m.data_ptr(), r.data_ptr(), a.data_ptr(),
+                                             t.data_ptr(), im.data_ptr(), ic.data_ptr(), zg.data_ptr(), B, H, W,
+                                             im.shape[1], im.shape[2], ws.data_ptr(), sums.data_ptr(),
+                                             sums.data_ptr() + 16),
+                   "fc3d_reproj_loss_fwd")
+        ctx.save_for_backward(sums, *ts)
+        return sums[4:8].clone()
+
+    @staticmethod
+    def backward(ctx, g_losses):
+        if any(ctx.needs_input_grad[1:]):
+            raise NotImplementedError("reproj_loss: only the gradient w.r.t. the predicted depth is implemented")
+        sums, z, m, r, a, t, im, ic, zg = ctx.saved_tensors
+        B, H, W, _ = z.shape
+        g = _dense(g_losses.to(torch.float32))
+        gz = torch.empty_like(z)
+        with _on_device(z.device):
+            _check(_lib.fc3d_reproj_loss_bwd(_stream(), g.data_ptr(), sums.data_ptr(), z.data_ptr(), m.data_ptr(), r.data_ptr(),
+                                             a.data_ptr(), t.data_ptr(), im.data_ptr(), ic.data_ptr(), zg.data_ptr(),
+                                             B, H, W, im.shape[1], im.shape[2], gz.data_ptr()),
+                   "fc3d_reproj_loss_bwd")
+        return gz, None, None, None, None, None, None, None
+
+
 # --------------------------------------------------------------------------- #
 # capture simulator (forward only)
 # --------------------------------------------------------------------------- #

@@ -192,6 +192,28 @@ int fc3d_reproject_bwd(void *stream, const float *g_zc, const float *g_out, cons
                        const float *inv, const float *T, const float *img, int B, int H, int W, int Hs, int Ws,
                        float *g_zp);
 
+/* The re-projection loss of reProj_IpGT, train_pytorch.py:188-207, on top of that chain, for
+ * a mask m that is already eroded (fc3d_box_filter mode 2, :184-186): zp = zp_hat * m (:188),
+ * zc and Ic' as fc3d_reproject_fwd computes them, and
+ *   sums[0] = sum (m (zcGT - zc))^2    sums[1] = sum (m (Ic - Ic'))^2      (cost_rms_mask numerators,
+ *   sums[2] = sum m |Ic - Ic'|         sums[3] = sum m                      utils_pytorch.py:161-162, :177)
+ * over the whole batch, and from them, with the reference's fp32 expressions (:163, :177, :209),
+ *   losses = [loss_Ic_L1 + loss_zc_rms, loss_zc_rms, loss_Ic_rms, loss_Ic_L1],
+ *   rms = sqrt(S / max(sums[3], 1e-6) + 1e-6),  loss_Ic_L1 = sums[2] / (sums[3] + 1)
+ * -- the four values reProj_IpGT returns (:211).
+ * zp_hat, mask, Ic, zcGT [B][H][W]; xy [B][H][W][2]; img [B][Hs][Ws]; sums, losses [4] device
+ * floats.  zc and Ic' are not stored.  workspace: fc3d_reproj_loss_workspace bytes, 16-byte
+ * aligned (one partial per 256 pixels, added in a fixed order: reproducible).  Backward:
+ * g_losses [4] device floats (the gradient w.r.t. losses) and the forward's sums -> g_zp_hat
+ * [B][H][W]; mask, Ic, zcGT, img, xy and the pose carry no gradient.                          */
+size_t fc3d_reproj_loss_workspace(int B, int H, int W);
+int fc3d_reproj_loss_fwd(void *stream, const float *zp_hat, const float *mask, const float *xy, const float *inv,
+                         const float *T, const float *img, const float *Ic, const float *zcGT, int B, int H, int W,
+                         int Hs, int Ws, void *workspace, float *sums, float *losses);
+int fc3d_reproj_loss_bwd(void *stream, const float *g_losses, const float *sums, const float *zp_hat,
+                         const float *mask, const float *xy, const float *inv, const float *T, const float *img,
+                         const float *Ic, const float *zcGT, int B, int H, int W, int Hs, int Ws, float *g_zp_hat);
+
 /* ------------------------------------------------------------------------ */
 /* the capture simulator around the path (forward_model, train_pytorch.py:     */
 /* 79-118; the reference runs it without gradients, so these are forward only)  */

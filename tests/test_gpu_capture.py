@@ -42,14 +42,17 @@ def test_forward_model_and_reproj_vs_oracle(env, monkeypatch, fused):
                  scale=rs.rand(B, 1, 1, 1).astype(np.float32))
     d = lambda a: torch.from_numpy(a).cuda()  # noqa: E731
     t = torch.from_numpy
+    # dots on a bright background: the capture clears the 0.05 threshold over whole regions, so the
+    # eroded mask of the re-projection loss is not empty
+    pat_np = (0.5 + 0.5 * synth.dot_pattern(H, W)).astype(np.float32).reshape(1, H, W, 1)
     out = capture.forward_model(d(sc["z_p"]), d(sc["z_c"]), d(sc["pose_p2c"]), L, True, N,
-                                {k: d(v) for k, v in noise.items()}, fused=fused)
+                                {k: d(v) for k, v in noise.items()}, pattern=d(pat_np), fused=fused)
     Ic_s, Ic_m, xyz, xy, zc, zp, pose, zp_full, Ic, Ip_coded, Ic_s_full = out
     assert Ic_s.shape == (B, N, N, 1) and xyz.shape == (B, N, N, 3) and Ip_coded.shape == (B, H, W, 1)
 
     # the same composition with the oracle on the CPU
     z_p, z_c, pose_c = t(sc["z_p"]), t(sc["z_c"]), t(sc["pose_p2c"])
-    Ip = t(synth.dot_pattern(H, W)).view(1, H, W, 1)
+    Ip = t(pat_np)
     dy = F.pad(z_p[:, 1:] - z_p[:, :-1], (0, 0, 0, 0, 0, 1))
     dx = F.pad(z_p[:, :, 1:] - z_p[:, :, :-1], (0, 0, 0, 1, 0, 0))
     refl = torch.cos(torch.atan(torch.sqrt(dy ** 2 + dx ** 2) / 100e-6)) * 0.8 + 0.2
@@ -82,6 +85,7 @@ def test_forward_model_and_reproj_vs_oracle(env, monkeypatch, fused):
     (l1 + lz).backward()
     assert abs(float(loss) - float(l1 + lz)) < 1e-4 * abs(float(l1 + lz))
     assert rel_err(zhat.grad.cpu().numpy(), zh.grad.numpy()) < 2e-3      # L1 loss: sign flips at |diff|~0 pixels
+    assert float(me.sum()) > 0 and float(zh.grad.abs().max()) > 0
 
 
 @pytest.mark.parametrize("B,H,W", [(2, 96, 128), (3, 37, 53), (1, 4, 5), (1, 1, 1), (1, 8, 4100)])
@@ -159,6 +163,36 @@ def test_box_filter_vs_avg_pool(env, B, H, W):
         assert rel_err(capture.local_norm(v, 5).cpu().numpy(), (v.cpu() / (pool(v.cpu(), 5) + 0.01)).numpy()) < 1e-5
     with pytest.raises(RuntimeError):
         ops.box_filter(img.cuda(), 4, "mean")
+
+
+@pytest.mark.parametrize("B,H,W,N", [(2, 96, 128, 64), (3, 41, 57, None)])
+def test_reproj_loss_kernels_match_composed(env, monkeypatch, B, H, W, N):
+    """The loss kernels (masked re-projection sums, forward and backward) against the same loss
+    composed from the chain operators and tensor reductions: the four values and d loss / d depth."""
+    G, O, capture, synth = env["G"], env["O"], env["capture"], env["synth"]
+    monkeypatch.setattr(G, "get_intrinsic", K_fn(W, H))
+    O.PSFs_np = synth.make_psfs(21, 5, "disc")
+    sc = synth.make_scene(B, H, W, 97)
+    d = lambda a: torch.from_numpy(a).cuda()  # noqa: E731
+    # a dense pattern: with the dot array the 5x5 erosion of (Ic > 0.05) leaves nothing to compare
+    pat = d(np.random.RandomState(98).uniform(0.5, 1.0, (1, H, W, 1)).astype(np.float32))
+    with torch.no_grad():
+        out = capture.forward_model(d(sc["z_p"]), d(sc["z_c"]), d(sc["pose_p2c"]), 21, True, N, pattern=pat)
+    Ic_s, Ic_m, xyz, xy, zc, zp, pose, _, Ic, Ip_coded, _ = out
+    assert float(capture.erode(Ic_m, 5).mean()) > 0.3
+    torch.manual_seed(5)
+    z0 = xyz[..., 2:3] + 0.003 * torch.randn_like(zc)          # a prediction of the projector-frame depth
+    res = {}
+    for fused in (True, False):
+        zh = z0.clone().requires_grad_(True)
+        vals = capture.reProj_IpGT(zh, pose, xy, Ic, zc, Ic_m, Ip_coded, fused=fused)
+        (vals[0] + 0.5 * vals[2]).backward()                   # the unused RMS term gets a gradient too
+        res[fused] = ([float(v) for v in vals], zh.grad.clone())
+    for a, b in zip(res[True][0], res[False][0]):
+        assert abs(a - b) <= 2e-5 * abs(b), (res[True][0], res[False][0])
+    ga, gb = res[True][1], res[False][1]
+    assert float((ga - gb).abs().max()) <= 1e-4 * float(gb.abs().max())
+    assert float(Ic_m.sum()) > 0 and float(gb.abs().max()) > 0
 
 
 def test_train_step_runs(env, monkeypatch):
