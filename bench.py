@@ -228,6 +228,18 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # the replayed step must give what eager launches give (guards the timed number against a
+    # capture that silently computes something else)
+    replay_ok = None
+    if launch == "hip_graph":
+        Ic_g, gr_g = (x.clone() for x in gf.replay())
+        Ic_e = step()
+        gr_e = tens["pat"].grad
+        replay_ok = bool(torch.equal(Ic_g, Ic_e)) and \
+            float((gr_g - gr_e).abs().max()) <= 1e-5 * float(gr_e.abs().max())
+        if not replay_ok:
+            print("[bench] WARNING: graph replay and eager results differ", file=sys.stderr)
+
     # same K steps again with an event pair around every kernel launch
     profiler.enable(True)
     profiler.report()
@@ -263,7 +275,7 @@ def main():
                                    f"{cfg['K']}x{cfg['K']} '{args.psf_kind}' PSFs, pose theta<={cfg['theta_deg']}deg; "
                                    "codePattern -> warp_p2c fwd + bwd to pattern[...,0]",
                        "global_batch": world * B, "parallelism": f"batch-sharded x{world}, no collective",
-                       "launch": launch},
+                       "launch": launch, "replay_matches_eager": replay_ok},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
                          "kernel_avg_us": dk["avg_us"], "alg_bytes_per_launch": dk["alg_bytes_per_launch"],
