@@ -331,12 +331,31 @@ __global__ __launch_bounds__(NT) void box_kernel(const float* __restrict__ in, i
     const int b = blockIdx.z;
     const int x0 = blockIdx.x * BOX_TW, y0 = blockIdx.y * BOX_TH;
     const float* img = in + (long)b * H * W;
-    for (int ty = threadIdx.x >> 6; ty < LH; ty += NT / 64) {
-        const int gy = y0 - r + ty;
-        const bool rowok = gy >= 0 && gy < H;
-        for (int tx = threadIdx.x & 63; tx < LW; tx += 64) {
-            const int gx = x0 - r + tx;
-            tile[ty * TP + tx] = (rowok && gx >= 0 && gx < W) ? img[(long)gy * W + gx] : 0.0f;
+    {
+        // six rows per wavefront at a time, every load from a clamped (always valid) address and
+        // issued before the first use: one memory latency per batch instead of one per row
+        constexpr int BATCH = 6, WAVES = NT / 64;
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        const int gxa = x0 - r + lane, gxb = gxa + 64;          // LW <= 128: two columns per lane cover a row
+        const bool oka = gxa >= 0 && gxa < W, okb = gxb >= 0 && gxb < W;
+        const unsigned ca = (unsigned)min(max(gxa, 0), W - 1), cb = (unsigned)min(max(gxb, 0), W - 1);
+        for (int tb = wv; tb < LH; tb += WAVES * BATCH) {
+            float va[BATCH], vb[BATCH];
+#pragma unroll
+            for (int i = 0; i < BATCH; ++i) {
+                const unsigned row = (unsigned)min(max(y0 - r + tb + WAVES * i, 0), H - 1) * (unsigned)W;
+                va[i] = ld_at(img, row + ca);
+                vb[i] = ld_at(img, row + cb);
+            }
+#pragma unroll
+            for (int i = 0; i < BATCH; ++i) {
+                const int ty = tb + WAVES * i, gy = y0 - r + ty;
+                if (ty < LH) {
+                    const bool rowok = gy >= 0 && gy < H;
+                    tile[ty * TP + lane] = (rowok && oka) ? va[i] : 0.0f;
+                    if (lane + 64 < LW) tile[ty * TP + lane + 64] = (rowok && okb) ? vb[i] : 0.0f;
+                }
+            }
         }
     }
     __syncthreads();
@@ -347,6 +366,7 @@ __global__ __launch_bounds__(NT) void box_kernel(const float* __restrict__ in, i
         float a = 0.0f;
         for (int d = 0; d < k; ++d) a += row[d];
         dst[0] = a;
+#pragma unroll
         for (int i = 1; i < BOX_SEG; ++i) {
             a = (a + row[i + k - 1]) - row[i - 1];
             dst[i] = a;
@@ -363,10 +383,11 @@ __global__ __launch_bounds__(NT) void box_kernel(const float* __restrict__ in, i
     const float* col = hs + ty0 * HP + x;
     float a = 0.0f;
     for (int d = 0; d < k; ++d) a += col[d * HP];
+#pragma unroll
     for (int j = 0; j < ROWS; ++j) {
         const int gy = y0 + ty0 + j;
-        if (gy >= H) break;
         if (j > 0) a = (a + col[(j + k - 1) * HP]) - col[(j - 1) * HP];
+        if (gy >= H) continue;
         const float mean = a / area;
         float v;
         if (MODE == kBoxMean) v = mean;
