@@ -315,6 +315,38 @@ def g7_reproj(G):
          g_ic=g_ic, g_zc=g_zc, grad_zp=zpt.grad, cx=np.array(W / 2), cy=np.array(H / 2))
 
 
+def g8_utils(U):
+    """The producers and post-processing around the path, from the reference's utils_pytorch:
+    dotArray pattern, withReflectance, ln, the masked losses (values and gradients)."""
+    import torch.nn.functional as F
+    pat_small = U.gen_pattern(1, 200, 300, 2, 0, "dotArray", 16, device='cpu')
+    pat_native = U.gen_pattern(1, 800, 1200, 1, 0, "dotArray", 16, device='cpu')
+    B, H, W = 2, 40, 56
+    rs = np.random.RandomState(91)
+    z = depth_with_outliers(B, H, W, 92)
+    I = rs.uniform(0, 1, (B, H, W, 1)).astype(np.float32)
+    refl = U.withReflectance(t(I), t(z))
+    dy, dx = U.image_gradients(t(z))
+    Im = rs.uniform(0, 1, (B, H, W, 1)).astype(np.float32)
+    ln17, ln5 = U.ln(t(Im)), U.ln(t(Im), kernelsize=5, constant=0.02)
+    mask = (rs.uniform(0, 1, (B, H, W, 1)) > 0.06).astype(np.float32)
+    erode5 = (F.avg_pool2d(t(mask).permute(0, 3, 1, 2), kernel_size=5, stride=1, padding=2)
+              .permute(0, 2, 3, 1) > 0.999).float()                      # train_pytorch.py:184-186
+    GT = rs.uniform(0.7, 0.9, (B, H, W, 1)).astype(np.float32)
+    hat0 = (GT + rs.normal(0, 0.01, GT.shape)).astype(np.float32)
+    out = {}
+    for name, fn in (("rms", U.cost_rms_mask), ("l1", U.cost_L1_mask), ("grad", U.cost_grad_mask)):
+        hat = t(hat0).requires_grad_(True)
+        v = fn(t(GT), hat, t(mask))
+        v.backward()
+        out["loss_" + name] = v.detach()
+        out["grad_" + name] = hat.grad
+    save("g8_utils", pat_small_bits=np.packbits(pat_small[0, :, :, 0].numpy().astype(np.uint8).reshape(-1)),
+         pat_small_ch1_equal=np.array(bool(torch.equal(pat_small[..., 0], pat_small[..., 1]))),
+         pat_native_bits=np.packbits(pat_native[0, :, :, 0].numpy().astype(np.uint8).reshape(-1)),
+         z=z, I=I, refl=refl, dy=dy, dx=dx, Im=Im, ln17=ln17, ln5=ln5, mask=mask, erode5=erode5, GT=GT, hat=hat0, **out)
+
+
 def g0_rays(G):
     """pixel_to_ray_array / pixel_to_ray / get_intrinsic / z2pointcloud constants."""
     r = G.pixel_to_ray_array(width=24, height=10)
@@ -341,6 +373,9 @@ def main():
     g5_visible(G)
     g6_warp(G)
     g7_reproj(G)
+    import utils_pytorch as U
+    assert U.__file__.startswith(args.ref)
+    g8_utils(U)
 
 
 if __name__ == "__main__":

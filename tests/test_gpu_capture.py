@@ -140,6 +140,18 @@ def test_capture_kernels_match_composed_operators(env, monkeypatch, B, H, W):
     assert torch.equal(valid.cpu(), Im)
 
 
+def test_capture_kernels_vs_reference_fixture(env, golden):
+    """Shading, local normalisation and erosion kernels against outputs of the reference's
+    utils_pytorch (withReflectance, ln, the avg-pool erosion)."""
+    from fc3d import ops
+    g = golden("g8_utils")
+    d = lambda a: torch.from_numpy(a).cuda()  # noqa: E731
+    assert rel_err(ops.reflectance(d(g["I"]), d(g["z"])).cpu().numpy(), g["refl"]) < 1e-5
+    assert rel_err(ops.box_filter(d(g["Im"]), 17, "local_norm", 0.01).cpu().numpy(), g["ln17"]) < 1e-5
+    assert rel_err(ops.box_filter(d(g["Im"]), 5, "local_norm", 0.02).cpu().numpy(), g["ln5"]) < 1e-5
+    assert np.array_equal(ops.box_filter(d(g["mask"]), 5, "erode").cpu().numpy(), g["erode5"])
+
+
 @pytest.mark.parametrize("B,H,W", [(2, 37, 53), (1, 64, 128), (3, 5, 3), (1, 100, 70)])
 def test_box_filter_vs_avg_pool(env, B, H, W):
     """Local normalisation and mask erosion against F.avg_pool2d on the CPU: erosion of a 0/1

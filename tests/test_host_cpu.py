@@ -89,6 +89,30 @@ def test_dropin_module_surface(golden):
         G.gen_visible_mask(torch.zeros(1, 2, 2, 2), "nearest")
 
 
+def test_producers_and_postprocessing_match_reference_fixture(golden):
+    """The tensor-op forms of the pattern generator, shading, local normalisation, erosion and
+    the masked losses (fc3d.synth / fc3d.capture) against outputs of the reference's utils_pytorch."""
+    from fc3d import capture, synth
+    g = golden("g8_utils")
+    t = torch.from_numpy
+    bits = lambda a: np.packbits(a.astype(np.uint8).reshape(-1))  # noqa: E731
+    assert np.array_equal(bits(synth.dot_pattern(200, 300, 100, 150)), g["pat_small_bits"])
+    assert np.array_equal(bits(synth.dot_pattern(800, 1200)), g["pat_native_bits"])       # default grid = 100 x 150 there
+    assert bool(g["pat_small_ch1_equal"])                                                 # every layer holds the same image
+    dy, dx = capture.image_gradients(t(g["z"]))
+    assert torch.equal(dy, t(g["dy"])) and torch.equal(dx, t(g["dx"]))
+    assert torch.equal(capture.with_reflectance(t(g["I"]), t(g["z"])), t(g["refl"]))
+    assert torch.equal(capture.local_norm(t(g["Im"]), 17, 0.01), t(g["ln17"]))
+    assert torch.equal(capture.local_norm(t(g["Im"]), 5, 0.02), t(g["ln5"]))
+    assert torch.equal(capture.erode(t(g["mask"]), 5), t(g["erode5"]))
+    for name, fn in (("rms", capture.cost_rms_mask), ("l1", capture.cost_L1_mask), ("grad", capture.cost_grad_mask)):
+        hat = t(g["hat"]).clone().requires_grad_(True)
+        v = fn(t(g["GT"]), hat, t(g["mask"]))
+        v.backward()
+        assert abs(float(v) - float(g["loss_" + name])) <= 1e-6 * abs(float(g["loss_" + name])), name
+        assert float((hat.grad - t(g["grad_" + name])).abs().max()) <= 1e-6 * float(np.abs(g["grad_" + name]).max()), name
+
+
 def test_unets_match_reference_parameter_count():
     from fc3d import nets
     nxy = sum(p.numel() for p in nets.UNet_xy().parameters())
