@@ -160,3 +160,63 @@ def test_c4_large_kernels(env, monkeypatch):
         _, _, mx, _ = env["ops"].CodePatternFn.apply(t["pat"], t["z_p"], O._device_psfs(t["pat"].device), O._layer_grid(L), True)
         got = Ip[0, y0 + m:y0 + h - m, x0 + m:x0 + w - m, 0].cpu().numpy() * (float(mx[0]) + 1e-10)
         assert rel_err(got, raw_r[0, m:h - m, m:w - m, 0].numpy()) < TOL, K
+
+
+@pytest.mark.parametrize("name", ["C2", "C5"])
+def test_capture_and_loss_kernels_full_size(env, monkeypatch, name):
+    """The capture-simulator and loss kernels at the benchmark size: the warp straight from the
+    depth maps equals the composed operators bit for bit; the sensor model equals the tensor
+    expression evaluated by torch on the CPU for the first and last image; erosion equals the
+    avg-pool form; the loss kernels agree with the composed loss and its gradient."""
+    import torch.nn.functional as F
+    from fc3d import capture
+    G, ops = env["G"], env["ops"]
+    wl, cfg, t = load(env, name, monkeypatch)
+    B, H, W = cfg["B"], cfg["H"], cfg["W"]
+    dev = t["z_p"].device
+    rs = np.random.RandomState(11)
+    d = lambda a: torch.from_numpy(a).cuda()  # noqa: E731
+    Ip = d(rs.uniform(0.3, 1.0, (B, H, W, 1)).astype(np.float32))
+
+    Ic_ref, gp_ref, gc_ref = G.warp_p2c(Ip, t["coord_p"], t["coord_c"], t["pose"])
+    vis_ref = G.gen_visible_mask(gp_ref, "all")
+    xy = capture._rays_xy(H, W, dev).unsqueeze(0).expand(B, -1, -1, -1)
+    xyz_ref = G.bilinear_sampler(torch.cat([xy, t["z_p"]], dim=-1), gc_ref) * vis_ref
+    rx, ry = G._separable_rays(W, H, dev)
+    T_p2c, T_c2p, _ = ops.pose_transforms(t["pose"], G._intrinsics_for(B, dev), want_fwd=True, want_inv=True)
+    Ic, xyz, mask = ops.capture_warp(Ip, t["z_p"], t["z_c"], rx, ry, T_p2c, T_c2p)
+    assert torch.equal(Ic, Ic_ref) and torch.equal(xyz, xyz_ref)
+    assert torch.equal(mask.view(B, H, W, 1).float(), vis_ref)
+    del gp_ref, xyz_ref
+
+    off, sca = rs.rand(B, 1, 1, 1).astype(np.float32), rs.rand(B, 1, 1, 1).astype(np.float32)
+    gau = rs.randn(B, H, W, 1).astype(np.float32)
+    scaled, valid = ops.capture_post(Ic, d(off), d(gau), d(sca), mask)
+    tt = torch.from_numpy
+    for b in (0, B - 1):
+        Ie = Ic[b:b + 1].cpu() + tt(off[b:b + 1]) * 0.05 + tt(gau[b:b + 1]) * 0.005
+        Is = torch.clamp(Ie / Ie.amax(dim=(1, 2), keepdim=True) * (tt(sca[b:b + 1]) * 0.3 + 0.7), 0.0, 1.0)
+        assert torch.equal(scaled[b:b + 1].cpu(), Is)
+        assert torch.equal(valid[b:b + 1].cpu(), (Is > 0.05).float() * vis_ref[b:b + 1].cpu())
+    assert float(valid.mean()) > 0.3
+
+    pool = lambda m, k: F.avg_pool2d(m.permute(0, 3, 1, 2), k, stride=1, padding=k // 2).permute(0, 2, 3, 1)  # noqa: E731
+    for k in (5, 9):
+        assert torch.equal(ops.box_filter(valid, k, "erode"), (pool(valid, k) > 0.999).float())
+    ln = ops.box_filter(scaled, 17, "local_norm", 0.01)
+    assert rel_err(ln.cpu().numpy(), (scaled / (pool(scaled, 17) + 0.01)).cpu().numpy()) < 1e-5
+
+    # the re-projection loss on these captures, for a noisy prediction of the camera-view depth
+    torch.manual_seed(3)
+    z0 = xyz[..., 2:3] + 0.003 * torch.randn_like(Ic)
+    res = {}
+    for fused in (True, False):
+        zh = z0.clone().requires_grad_(True)
+        vals = capture.reProj_IpGT(zh, t["pose"], xy, Ic, t["z_c"], valid, Ip, fused=fused)
+        (vals[0] + 0.5 * vals[2]).backward()
+        res[fused] = ([float(v) for v in vals], zh.grad)
+    for a, b in zip(res[True][0], res[False][0]):
+        assert abs(a - b) <= 5e-5 * abs(b), (res[True][0], res[False][0])
+    ga, gb = res[True][1], res[False][1]
+    assert float(gb.abs().max()) > 0
+    assert float((ga - gb).abs().max()) <= 1e-4 * float(gb.abs().max())
