@@ -65,6 +65,16 @@ def main():
             step(fused)
         torch.cuda.synchronize()
         out[name] = (time.perf_counter() - t0) / a.steps
+    from fc3d.graphs import GraphedCapture
+    gcap = GraphedCapture(z_p, z_c, pose, noise, L, True, None)
+    for _ in range(a.warmup):
+        gcap.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        gcap.replay()
+    torch.cuda.synchronize()
+    out["graph"] = (time.perf_counter() - t0) / a.steps
     profiler.enable(True)
     profiler.report()
     for _ in range(a.steps):
@@ -100,7 +110,7 @@ def main():
         "higher_is_better": True, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{B}x{H}x{W}, L={L}, 5x5 PSFs: depth maps -> shaded pattern -> codePattern -> warp -> "
                                "sensor model, forward only"},
-        "composed_ms_per_step": 1e3 * out["composed"], "speedup_vs_composed": out["composed"] / out["fused"],
+        "graph_replay_ms_per_step": 1e3 * out["graph"], "composed_ms_per_step": 1e3 * out["composed"], "speedup_vs_composed": out["composed"] / out["fused"],
         "roofline": {"bound": "hbm", "kernel": "all kernels of one capture", "achieved": ALG_BYTES * px / (kus * 1e-6) / 1e9,
                      "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ALG_BYTES * px / (kus * 1e-6) / HBM_PEAK,
                      "traffic": None, "kernel_us": kus},

@@ -1,4 +1,4 @@
-"""HIP-graph replay of the image-formation step.
+"""HIP-graph replay of the image-formation step and of the capture simulator.
 
 One capture (codePattern -> warp_p2c forward, backward to pattern[...,0]) is eight short kernel
 launches plus two fills; issued one by one from Python (ctypes + autograd) they cost about 250 us
@@ -66,3 +66,36 @@ class GraphedImageFormation:
         """Runs the captured step on the current stream; returns (Ic, pattern.grad) static tensors."""
         self.graph.replay()
         return self.outputs[1], self.pattern.grad
+
+
+class GraphedCapture:
+    """Static-buffer replay of the capture simulator, fc3d.capture.forward_model (forward only):
+    shading -> codePattern -> warp from the depth maps -> sensor model, eight launches.  At small
+    batches those launches cost more host time than the kernels take; replaying them as one graph
+    removes that.
+
+    z_p, z_c, pose and the three noise tensors are the graph's input buffers: refill them in place
+    (``t.copy_(new)``) between replays.  ``replay()`` returns forward_model's tuple; its tensors are
+    static too and are overwritten by the next replay."""
+
+    def __init__(self, z_p, z_c, pose, noise, n_layers=21, is_conv_psf=True, crop=None, pattern=None,
+                 warmup: int = 3):
+        from . import capture
+        self.z_p, self.z_c, self.pose, self.noise = z_p, z_c, pose, noise
+        self._call = lambda: capture.forward_model(z_p, z_c, pose, n_layers, is_conv_psf, crop, noise, pattern,
+                                                   fused=True)
+        dev = z_p.device
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(max(1, warmup)):
+                self._call()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"), torch.no_grad():
+            self.outputs = self._call()
+
+    def replay(self):
+        self.graph.replay()
+        return self.outputs
