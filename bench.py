@@ -66,7 +66,7 @@ def parse():
                          "at the headline size that hides behind the kernels on a quiet host and is ~2%% faster "
                          "than replay, but one run in three measured 15%% slower, so replay is the default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
     return ap.parse_args()
 
 
@@ -120,7 +120,7 @@ def cpu_baseline(wl, seconds):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import fc3d_oracle as orc
     cfg = wl["cfg"]
-    Bs = min(2, cfg["B"])
+    Bs = min(4, cfg["B"])
     H, W, L = cfg["H"], cfg["W"], cfg["L"]
     t = torch.from_numpy
     z_p, z_c, pose = t(wl["z_p"][:Bs]), t(wl["z_c"][:Bs]), t(wl["pose_p2c"][:Bs])
@@ -147,10 +147,10 @@ def cpu_baseline(wl, seconds):
                 return best, n
 
     threads = torch.get_num_threads()
-    best, n = best_of(seconds, 50)
+    best, n = best_of(0.6 * seconds, 10 ** 6)          # bounded by time: about `seconds` of CPU work in all
     torch.set_num_threads(1)
     try:
-        best1, n1 = best_of(seconds / 2, 10)
+        best1, n1 = best_of(0.4 * seconds, 10 ** 6)
     finally:
         torch.set_num_threads(threads)
     return dict(value=Bs / best, unit="captures/s", cores=threads, kind="port",
