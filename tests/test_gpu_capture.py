@@ -93,7 +93,7 @@ def test_forward_model_and_reproj_vs_oracle(env, monkeypatch, fused):
     assert float(me.sum()) > 0 and float(zh.grad.abs().max()) > 0
 
 
-@pytest.mark.parametrize("B,H,W", [(2, 96, 128), (3, 37, 53), (1, 4, 5), (1, 1, 1), (1, 8, 4100)])
+@pytest.mark.parametrize("B,H,W", [(2, 96, 128), (3, 37, 53), (1, 4, 5), (1, 1, 1), (1, 8, 4100), (1, 800, 1200)])
 def test_capture_kernels_match_composed_operators(env, monkeypatch, B, H, W):
     """The capture kernels against the operators they stand for, on the same device inputs:
     warp straight from the depth maps == points + warp_p2c + bilinear_sampler (bit for bit, masks
