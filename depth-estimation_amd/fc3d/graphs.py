@@ -1,8 +1,8 @@
 """HIP-graph replay of the image-formation step and of the capture simulator.
 
-One capture (codePattern -> warp_p2c forward, backward to pattern[...,0]) is eight short kernel
-launches plus two fills; issued one by one from Python (ctypes + autograd) they cost about 250 us
-of host time per step, which is more than the kernels themselves take at 32x512x512.  Capturing
+One capture (codePattern -> warp_p2c forward, backward to pattern[...,0]) is nine short kernel
+launches; issued one by one from Python (ctypes + autograd) they cost 125-250 us of host time per
+step, which is as much as the kernels themselves take at 32x512x512 and far more at small batches.  Capturing
 the step once into a HIP graph (torch.cuda.CUDAGraph: hipStreamBeginCapture / hipGraphLaunch on
 ROCm) and replaying it removes that cost: the launches are the same, in the same order, on the
 same buffers; only the host-side issue changes.
