@@ -624,7 +624,7 @@ __global__ __launch_bounds__(NT) void code_pattern_bwd_max_kernel(
         const int qy = py + dy - pad, qx = px + dx - pad;
         if (qy >= 0 && qy < H && qx >= 0 && qx < W) {
             float* q = g_pat0 + img + (long)qy * W + qx;
-            *q = *q - corr * psf[(long)l * K * K + d];
+            *q = *q - corr * (psf ? psf[(long)l * K * K + d] : 1.0f);
         }
     }
 }
@@ -721,6 +721,135 @@ void code_pattern_fwd_roll_kernel(
     }
     key = wave_max(key);
     if (lane == 0) tilekey[kidx] = key;
+}
+
+// ---------------------------------------------------------------------------------------
+// is_conv_psf=False (optics_pytorch.py:110-112; what the reference's training loop runs): the
+// pattern gated by the in-range mask, no blur.  Pure streaming: every wavefront owns 1024
+// consecutive pixels of an image, 16 per lane as four 16-byte groups 256 pixels apart, and
+// publishes one max key (forward) or one partial of sum(g*out) (backward).
+// ---------------------------------------------------------------------------------------
+constexpr int FLAT_GROUPS = 4;                    // float4 groups per lane
+constexpr int FLAT_WAVE_PX = 64 * 4 * FLAT_GROUPS;
+
+__device__ __forceinline__ int flat_layer(float z, const fc3d_layer_grid& lg, const LayerFast& lf) {
+    bool amb;
+    int l = layer_fast(z, lg, lf, amb);
+    if (amb) l = layer_of(z, lg);
+    return l;
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(NT) void code_pattern_flat_fwd_kernel(
+    const float* __restrict__ pat0, long sb, long sh, long sw, const float* __restrict__ z, int H, int W,
+    fc3d_layer_grid lg, float* __restrict__ raw, uint8_t* __restrict__ layer_u8,
+    unsigned long long* __restrict__ tilekey) {
+    const int b = blockIdx.y;
+    const unsigned HW = (unsigned)H * (unsigned)W;
+    const int lane = threadIdx.x & 63;
+    const unsigned wave = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    const unsigned q0 = wave * FLAT_WAVE_PX;
+    const float* pimg = pat0 + (long)b * sb;
+    const float* zimg = z + (long)b * HW;
+    float* rimg = raw + (long)b * HW;
+    uint8_t* limg = layer_u8 ? layer_u8 + (long)b * HW : nullptr;
+    const LayerFast lf = layer_fast_setup(lg);
+    unsigned long long key = 0;
+    if (VEC) {
+        float4 pv[FLAT_GROUPS], zv[FLAT_GROUPS];
+#pragma unroll
+        for (int g = 0; g < FLAT_GROUPS; ++g) {
+            const unsigned q = min(q0 + g * 256u + lane * 4u, HW - 4u);    // clamped: always a valid group
+            pv[g] = ld_at(reinterpret_cast<const float4*>(pimg), q >> 2);
+            zv[g] = ld_at(reinterpret_cast<const float4*>(zimg), q >> 2);
+        }
+#pragma unroll
+        for (int g = 0; g < FLAT_GROUPS; ++g) {
+            const unsigned q = q0 + g * 256u + lane * 4u;
+            if (q >= HW) continue;
+            const unsigned y = q / (unsigned)W, x = q - y * (unsigned)W;   // W % 4 == 0: the group stays in one row
+            const float zz[4] = {zv[g].x, zv[g].y, zv[g].z, zv[g].w};
+            const float pp[4] = {pv[g].x, pv[g].y, pv[g].z, pv[g].w};
+            float a[4];
+            uint8_t lb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int l = flat_layer(zz[i], lg, lf);
+                a[i] = pp[i] * (l >= 0 ? 1.0f : 0.0f);       // a multiply: a non-finite pattern value still poisons the pixel
+                lb[i] = (uint8_t)l;
+                const uint32_t pos = 0xffffffffu - (uint32_t)((x + i) * (unsigned)H + y);   // first w, then first h
+                const unsigned long long k = ((unsigned long long)float_to_key(a[i]) << 32) | pos;
+                key = k > key ? k : key;
+            }
+            st_at(reinterpret_cast<float4*>(rimg), q >> 2, make_float4(a[0], a[1], a[2], a[3]));
+            if (limg) st_at(reinterpret_cast<uchar4*>(limg), q >> 2, make_uchar4(lb[0], lb[1], lb[2], lb[3]));
+        }
+    } else {
+        for (int i = 0; i < 4 * FLAT_GROUPS; ++i) {
+            const unsigned q = q0 + i * 64u + lane;
+            if (q >= HW) break;
+            const unsigned y = q / (unsigned)W, x = q - y * (unsigned)W;
+            const int l = flat_layer(zimg[q], lg, lf);
+            const float a = pimg[(long)y * sh + (long)x * sw] * (l >= 0 ? 1.0f : 0.0f);
+            const uint32_t pos = 0xffffffffu - (uint32_t)(x * (unsigned)H + y);
+            const unsigned long long k = ((unsigned long long)float_to_key(a) << 32) | pos;
+            key = k > key ? k : key;
+            rimg[q] = a;
+            if (limg) limg[q] = (uint8_t)l;
+        }
+    }
+    key = wave_max(key);
+    if (lane == 0) tilekey[(long)b * (gridDim.x * (NT / 64)) + wave] = key;   // 0 (below every real key) past the image
+}
+
+// g_pat0 = g / (max + 1e-10) where the pixel has a layer, 0 elsewhere, and one partial of sum(g*out)
+// per wavefront for the fix-up of the maximum's pixel (code_pattern_bwd_max_kernel, 1x1 footprint).
+template <bool VEC>
+__global__ __launch_bounds__(NT) void code_pattern_flat_bwd_kernel(
+    const float* __restrict__ g, const float* __restrict__ out, const uint8_t* __restrict__ layer_u8,
+    const float* __restrict__ max_in, unsigned HW, float* __restrict__ partial, float* __restrict__ g_pat0) {
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const unsigned wave = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    const unsigned q0 = wave * FLAT_WAVE_PX;
+    const float* gi = g + (long)b * HW;
+    const float* oi = out + (long)b * HW;
+    const uint8_t* li = layer_u8 + (long)b * HW;
+    float* gp = g_pat0 + (long)b * HW;
+    const float rden = 1.0f / (max_in[b] + 1e-10f);
+    float sgo = 0.0f;
+    if (VEC) {
+        float4 gv[FLAT_GROUPS], ov[FLAT_GROUPS];
+        uchar4 lv[FLAT_GROUPS];
+#pragma unroll
+        for (int k = 0; k < FLAT_GROUPS; ++k) {
+            const unsigned q = min(q0 + k * 256u + lane * 4u, HW - 4u);
+            gv[k] = ld_at(reinterpret_cast<const float4*>(gi), q >> 2);
+            ov[k] = ld_at(reinterpret_cast<const float4*>(oi), q >> 2);
+            lv[k] = ld_at(reinterpret_cast<const uchar4*>(li), q >> 2);
+        }
+#pragma unroll
+        for (int k = 0; k < FLAT_GROUPS; ++k) {
+            const unsigned q = q0 + k * 256u + lane * 4u;
+            if (q >= HW) continue;
+            sgo = fmaf(gv[k].x, ov[k].x, sgo); sgo = fmaf(gv[k].y, ov[k].y, sgo);
+            sgo = fmaf(gv[k].z, ov[k].z, sgo); sgo = fmaf(gv[k].w, ov[k].w, sgo);
+            float4 r;
+            r.x = lv[k].x != 255 ? gv[k].x * rden : 0.0f; r.y = lv[k].y != 255 ? gv[k].y * rden : 0.0f;
+            r.z = lv[k].z != 255 ? gv[k].z * rden : 0.0f; r.w = lv[k].w != 255 ? gv[k].w * rden : 0.0f;
+            st_at(reinterpret_cast<float4*>(gp), q >> 2, r);
+        }
+    } else {
+        for (int i = 0; i < 4 * FLAT_GROUPS; ++i) {
+            const unsigned q = q0 + i * 64u + lane;
+            if (q >= HW) break;
+            const float gq = gi[q];
+            sgo = fmaf(gq, oi[q], sgo);
+            gp[q] = li[q] != 255 ? gq * rden : 0.0f;
+        }
+    }
+    sgo = wave_sum(sgo);
+    if (lane == 0) partial[(long)b * (gridDim.x * (NT / 64)) + wave] = sgo;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1034,8 +1163,10 @@ extern "C" size_t fc3d_code_pattern_fwd_workspace(int B, int H, int W) {
     const long a = (long)cdiv(W, TX) * cdiv(H, TY);
     const long r = (long)cdiv(cdiv(W, Roll<7>::SW), NT / 64) * (NT / 64) * cdiv(H, kRollRows);
     const long sw = (long)cdiv(W, kSweepCols) * cdiv(H, kSweepTileRows);
+    const long fl = (long)cdiv(cdiv((long)H * W, FLAT_WAVE_PX), NT / 64) * (NT / 64);
     long m = a > r ? a : r;
     m = sw > m ? sw : m;
+    m = fl > m ? fl : m;
     return (size_t)B * m * sizeof(unsigned long long);
 }
 
@@ -1044,8 +1175,10 @@ extern "C" size_t fc3d_code_pattern_bwd_workspace(int B, int H, int W) {
     const long a = cdiv((long)H * W, RED_PX);
     const long r = (long)cdiv(cdiv(W, Roll<7>::SW), NT / 64) * (NT / 64) * cdiv(H, kRollRowsBwd);
     const long sw = (long)cdiv(W, kSweepCols) * cdiv(H, kSweepTileRows);
+    const long fl = (long)cdiv(cdiv((long)H * W, FLAT_WAVE_PX), NT / 64) * (NT / 64);
     long m = a > r ? a : r;
     m = sw > m ? sw : m;
+    m = fl > m ? fl : m;
     return (size_t)B * m * sizeof(float);
 }
 
@@ -1071,6 +1204,16 @@ extern "C" int fc3d_code_pattern_fwd(void* stream, const float* pat0, int64_t pa
     hipStream_t s = (hipStream_t)stream;
     const bool fits32 = (long)H * W < (1L << 30) && pat_sh >= 0 && pat_sw >= 0 &&
                         (long)(H - 1) * pat_sh + (long)(W - 1) * pat_sw < (1L << 30);   // byte offsets in 32 bits
+    if (!conv_flag && (long)H * W < (1L << 30)) {
+        const long HW = (long)H * W;
+        const dim3 gf(cdiv(cdiv(HW, FLAT_WAVE_PX), NT / 64), B);
+        const bool fvec = HW % 4 == 0 && W % 4 == 0 && HW >= 4 && pat_sw == 1 && pat_sh == W && pat_sb % 4 == 0 &&
+                          aligned16(pat0) && aligned16(z) && aligned16(raw_out) && (!layer_u8 || aligned4(layer_u8));
+        *keys_per_image = (int)(gf.x * (NT / 64));
+        if (fvec) FC3D_LAUNCH("code_pattern_fwd", code_pattern_flat_fwd_kernel<true>, gf, blk, 0, s, pat0, (long)pat_sb, (long)pat_sh, (long)pat_sw, z, H, W, grid, raw_out, layer_u8, (unsigned long long*)tilekey_u64);
+        else FC3D_LAUNCH("code_pattern_fwd", code_pattern_flat_fwd_kernel<false>, gf, blk, 0, s, pat0, (long)pat_sb, (long)pat_sh, (long)pat_sw, z, H, W, grid, raw_out, layer_u8, (unsigned long long*)tilekey_u64);
+        return FC3D_OK;
+    }
     if (conv_flag && Kh == Kw && fits32) {
 #define FC3D_FWD_ROLL_CASE(KV)                                                                                   \
     if (Kw == KV) {                                                                                              \
@@ -1140,6 +1283,15 @@ extern "C" int fc3d_code_pattern_bwd(void* stream, const float* g_out, const flo
     const long HW = (long)H * W;
     const int nred = cdiv(HW, RED_PX);
     float* partial = (float*)workspace;
+    if (!conv_flag && HW < (1L << 30)) {
+        const dim3 gf(cdiv(cdiv(HW, FLAT_WAVE_PX), NT / 64), B);
+        const bool fvec = HW % 4 == 0 && HW >= 4 && aligned16(g_out) && aligned16(out) && aligned16(g_pat0) && aligned4(layer_u8);
+        if (fvec) FC3D_LAUNCH("code_pattern_bwd", code_pattern_flat_bwd_kernel<true>, gf, dim3(NT), 0, s, g_out, out, layer_u8, max_in, (unsigned)HW, partial, g_pat0);
+        else FC3D_LAUNCH("code_pattern_bwd", code_pattern_flat_bwd_kernel<false>, gf, dim3(NT), 0, s, g_out, out, layer_u8, max_in, (unsigned)HW, partial, g_pat0);
+        FC3D_LAUNCH("code_pattern_bwd_max", code_pattern_bwd_max_kernel, dim3(B), dim3(NT), 0, s, (const float*)partial,
+                    (int)(gf.x * (NT / 64)), max_in, argmax_i32, layer_u8, (const float*)nullptr, H, W, 1, g_pat0);
+        return FC3D_OK;
+    }
     if (conv_flag && Kh == Kw && HW < (1L << 30)) {
         constexpr int R = kRollRowsBwd;
 #define FC3D_BWD_ROLL_CASE(KV)                                                                                   \

@@ -162,6 +162,35 @@ def test_code_pattern_vs_oracle_ragged(mods):
         assert np.array_equal(got, li[..., 0].numpy())
 
 
+def test_code_pattern_without_blur_vs_oracle(mods):
+    """is_conv_psf=False (the mode the reference's training loop runs): ragged and 4-divisible sizes,
+    images larger than one wavefront's run, out-of-range depths, a strided channel-0 view."""
+    O, orc = mods["O"], mods["orc"]
+    rs = np.random.RandomState(15)
+    for (B, H, W, L, dense) in ((2, 37, 53, 21, True), (1, 130, 260, 21, True), (3, 64, 96, 41, False), (1, 1, 1, 21, True),
+                                (2, 31, 44, 21, False), (1, 2, 2, 21, True)):
+        z = rs.uniform(0.67, 0.97, (B, H, W, 1)).astype(np.float32)          # some pixels beyond both ends of the range
+        pL = rs.uniform(0, 1, (B, H, W, L)).astype(np.float32)
+        gg = rs.uniform(-1, 1, (B, H, W, 1)).astype(np.float32)
+        if dense:
+            a = dev(np.ascontiguousarray(pL[..., 0:1])).requires_grad_(True)
+            out = O.codePattern(a, dev(z), is_conv_psf=False, n_layers=L)
+        else:
+            a = dev(pL).requires_grad_(True)                                  # channel 0 is a view with stride L
+            out = O.codePattern(a, dev(z), is_conv_psf=False)
+        out.backward(dev(gg))
+        pc = t(pL.copy()).requires_grad_(True)
+        ref = orc.codePattern(pc, t(z), None, False)
+        ref.backward(t(gg))
+        assert rel_err(out.detach().cpu().numpy(), ref.detach().numpy()) < TOL, (B, H, W)
+        # on the scale of the upstream gradient: at the maximum's pixel g/den and sum(g*out)/den cancel
+        # (completely so in a one-pixel image), which leaves rounding noise on either side
+        gd = np.abs(a.grad[..., 0:1].cpu().numpy() - pc.grad[..., 0:1].numpy()).max()
+        assert gd < TOL * max(float(pc.grad.abs().max()), float(np.abs(gg).max())), (B, H, W)
+        if not dense:
+            assert float(a.grad[..., 1:].abs().max()) == 0.0
+
+
 def test_code_pattern_argmax_tie_break(mods):
     """Binary pattern => many pixels share the maximum; the gradient of the max must land
     on the smallest-w-then-smallest-h one, as torch's two-stage max does."""
