@@ -5,12 +5,14 @@
 // 64-bit key (ordered value | position priority) and the normalisation pass reduces an image's
 // keys.  The gradient flows to channel 0 of the pattern only.
 //
-// Three kernel families, picked by PSF size:
-//   rolling-row (3x3, 5x5, 7x7; near the end of this file): one pixel column per lane, column
-//       neighbours through wavefront shifts, PSF weights of the lane's layer in registers;
-//   layer sweep (9x9 ... 33x33 odd; after the rolling-row kernels): 64 columns x 4 rows per
-//       wavefront, input tile in LDS, one depth layer at a time with the PSF in scalar registers;
-//   generic 64x16 LDS tiles (everything else: even or non-square PSFs, 1x1, is_conv_psf=False):
+// Four kernel families, picked by mode and PSF size:
+//   rolling-row (3x3, 5x5, 7x7): one pixel column per lane, column neighbours through wavefront
+//       shifts, PSF weights of the lane's layer in registers;
+//   flat (is_conv_psf=False; after the rolling-row kernels): no blur, 1024 consecutive pixels per
+//       wavefront, pure streaming;
+//   layer sweep (9x9 ... 33x33 odd; after the flat kernels): 16 x 16 pixels per wavefront, input
+//       tile in LDS, one depth layer at a time with the PSF in scalar registers;
+//   generic 64x16 LDS tiles (everything else: even or non-square PSFs, 1x1):
 //       the backward pass first sums g*out per image (deterministic two-level sum), then
 //       evaluates the transposed convolution in gather form: every output pixel walks its K x K
 //       neighbours p and uses the PSF of *p's* layer.

@@ -35,6 +35,7 @@ NAMES = (
     ("bilinear_bwd_img_merge_kernel", "bilinear_bwd_img_merge"),
     ("bilinear_bwd_img_overflow_kernel", "bilinear_bwd_img_overflow"), ("points_fwd_kernel", "points_fwd"),
     ("code_pattern_fwd_sweep_kernel", "code_pattern_fwd"), ("code_pattern_bwd_sweep_kernel", "code_pattern_bwd"),
+    ("code_pattern_flat_fwd_kernel", "code_pattern_fwd"), ("code_pattern_flat_bwd_kernel", "code_pattern_bwd"),
     ("zero_fill_kernel", "zero_fill"), ("reflectance_kernel", "reflectance"),
     ("capture_project_kernel", "capture_project_splat"), ("capture_sample_kernel", "capture_sample"),
     ("capture_peak_kernel", "capture_peak"), ("capture_sensor_kernel", "capture_sensor"),
