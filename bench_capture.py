@@ -33,7 +33,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--no-conv", action="store_true",
+                    help="is_conv_psf=False, the mode the reference's training loop runs (train_pytorch.py:51-52)")
     a = ap.parse_args()
+    conv = not a.no_conv
     if not torch.cuda.is_available():
         sys.exit("bench_capture.py needs a GPU (the HIP path has no CPU fallback)")
     import geometry_pytorch as G
@@ -53,7 +56,7 @@ def main():
 
     def step(fused):
         with torch.no_grad():
-            return capture.forward_model(z_p, z_c, pose, L, True, None, noise, fused=fused)
+            return capture.forward_model(z_p, z_c, pose, L, conv, None, noise, fused=fused)
 
     out = {}
     for name, fused in (("fused", True), ("composed", False)):
@@ -66,7 +69,7 @@ def main():
         torch.cuda.synchronize()
         out[name] = (time.perf_counter() - t0) / a.steps
     from fc3d.graphs import GraphedCapture
-    gcap = GraphedCapture(z_p, z_c, pose, noise, L, True, None)
+    gcap = GraphedCapture(z_p, z_c, pose, noise, L, conv, None)
     for _ in range(a.warmup):
         gcap.replay()
     torch.cuda.synchronize()
@@ -108,8 +111,8 @@ def main():
         "metric": "simulated captures/sec, forward only (secondary; whole forward_model)", "value": B / out["fused"],
         "unit": "captures/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * out["fused"],
         "higher_is_better": True, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{B}x{H}x{W}, L={L}, 5x5 PSFs: depth maps -> shaded pattern -> codePattern -> warp -> "
-                               "sensor model, forward only"},
+        "config": {"workload": f"{B}x{H}x{W}, L={L}, " + ("5x5 PSFs" if conv else "no blur (is_conv_psf=False)") +
+                               ": depth maps -> shaded pattern -> codePattern -> warp -> sensor model, forward only"},
         "graph_replay_ms_per_step": 1e3 * out["graph"], "composed_ms_per_step": 1e3 * out["composed"], "speedup_vs_composed": out["composed"] / out["fused"],
         "roofline": {"bound": "hbm", "kernel": "all kernels of one capture", "achieved": ALG_BYTES * px / (kus * 1e-6) / 1e9,
                      "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ALG_BYTES * px / (kus * 1e-6) / HBM_PEAK,

@@ -29,6 +29,21 @@ def test_cabi_exports_every_declared_symbol():
     # 8 x 128 for the 64-column x 4-row wavefronts of the large-PSF kernels
     assert lib.fc3d_code_pattern_fwd_workspace(32, 512, 512) == 32 * 1024 * 8
     assert lib.fc3d_bilinear_bwd_img_workspace(2, 64, 96, 1, 64, 96) == 2 * 24 * (16 + 1024 * 4)
+    # the entry points around the path: one partial maximum per 4096 pixels (at most 256 per image),
+    # one float4 partial per 256 pixels
+    assert lib.fc3d_capture_post_workspace(32, 512, 512) == 32 * 64 * 4
+    assert lib.fc3d_capture_post_workspace(1, 4096, 4096) == 256 * 4
+    assert lib.fc3d_reproj_loss_workspace(2, 64, 64) == 2 * 16 * 16
+    assert lib.fc3d_capture_post_workspace(0, 4, 4) == 0 and lib.fc3d_reproj_loss_workspace(1, 0, 4) == 0
+    one = 16                                    # any non-null value: arguments are checked before they are used
+    assert lib.fc3d_box_filter(None, one, 1, 8, 8, 4, 0, 0.0, one + 64) == -1     # even window
+    assert lib.fc3d_box_filter(None, one, 1, 8, 8, 35, 0, 0.0, one + 64) == -1    # window beyond 33
+    assert lib.fc3d_box_filter(None, one, 1, 8, 8, 5, 3, 0.0, one + 64) == -1     # unknown mode
+    assert lib.fc3d_box_filter(None, one, 1, 8, 8, 5, 0, 0.0, one) == -1          # in place
+    assert lib.fc3d_capture_post(None, one, one, one, one, one, 1, 8, 8, one, one, None) == -1
+    assert lib.fc3d_capture_warp_fwd(None, one, one, one, one, one, one, one, 1, 8, 8, one, None, one, 0, None, None) == -1
+    assert lib.fc3d_reflectance_fwd(None, one, -1, one, 1, 8, 8, one) == -1            # negative batch stride
+    assert lib.fc3d_reproj_loss_fwd(None, one, one, None, one, one, one, one, one, 1, 8, 8, 8, 8, one, one, one) == -1
 
 
 def test_layer_grid_matches_reference_tables(golden):
