@@ -886,8 +886,15 @@ constexpr int kSweepRows = FC3D_SWEEP_ROWS;       // output rows per lane
 constexpr int kSweepTileRows = (64 / kSweepCols) * kSweepRows;
 #define FC3D_FOR_SWEEP_K(X) X(9) X(11) X(13) X(15) X(17) X(19) X(21) X(23) X(25) X(27) X(29) X(31) X(33)
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// Packed multiply-adds (v_pk_fma_f32: two per lane and instruction): a PSF row is consumed in pairs
+// of neighbouring columns, even and odd partial sums added at the end.  Measured per PSF size at
+// 8x512x512: the forward kernel gains from 15x15 on (15 %-25 %; 11x11 and 13x13 lose to the register
+// shuffling the pairs need), the backward kernel from 13x13 on (6-10 %).
 template <int K, int R, int CW>
 struct Sweep {
+    static constexpr bool PK_FWD = K >= 15, PK_BWD = K >= 13;
     static constexpr int PAD = (K - 1) / 2;
     static constexpr int NG = 64 / CW;            // row groups of lanes
     static constexpr int TR = NG * R;             // output rows per wavefront
@@ -933,6 +940,7 @@ __global__ __launch_bounds__(64) void code_pattern_fwd_sweep_kernel(
     const float* __restrict__ psf, int H, int W, fc3d_layer_grid lg, float* __restrict__ raw,
     uint8_t* __restrict__ layer_u8, unsigned long long* __restrict__ tilekey) {
     using S = Sweep<K, R, CW>;
+    constexpr bool PK = S::PK_FWD;
     constexpr int PAD = S::PAD, LW = S::LW, NRG = R + K - 1;       // NRG: input rows one row group reads
     extern __shared__ float smem[];               // [NR][LW]
     const int lane = threadIdx.x, col = lane % CW, grp = lane / CW;
@@ -970,9 +978,13 @@ __global__ __launch_bounds__(64) void code_pattern_fwd_sweep_kernel(
 #pragma unroll
         for (int o = 0; o < R; ++o)
             if (__ballot(lay[o] == l) != 0ull) rows |= 1u << o;
-        float acc[R];
+        float acc[R];                                            // one of the two sets is used, per PK
+        f2 acc2[R];
 #pragma unroll
-        for (int o = 0; o < R; ++o) acc[o] = 0.0f;
+        for (int o = 0; o < R; ++o) {
+            acc[o] = 0.0f;
+            acc2[o] = f2{0.0f, 0.0f};
+        }
         // Input rows R-1 .. K-1 feed all R output rows: that part is straight-line code (R scalar
         // loads of a PSF row, R*K multiply-adds) so that the loads run ahead of the arithmetic; the
         // first and last R-1 input rows feed fewer output rows and take the branchy form.
@@ -992,8 +1004,15 @@ __global__ __launch_bounds__(64) void code_pattern_fwd_sweep_kernel(
                 const int dy = r - o;
                 if (FULL || (((rows >> o) & 1u) && dy >= 0 && dy < K)) {
                     const float* wr = wbase + (R - 1 - o) * K;
+                    if (PK) {
 #pragma unroll
-                    for (int dx = 0; dx < K; ++dx) acc[o] = fmaf(wr[dx], in[dx], acc[o]);
+                        for (int dx = 0; dx + 1 < K; dx += 2)
+                            acc2[o] = __builtin_elementwise_fma(f2{wr[dx], wr[dx + 1]}, f2{in[dx], in[dx + 1]}, acc2[o]);
+                        acc2[o].x = fmaf(wr[K - 1], in[K - 1], acc2[o].x);  // K is odd
+                    } else {
+#pragma unroll
+                        for (int dx = 0; dx < K; ++dx) acc[o] = fmaf(wr[dx], in[dx], acc[o]);
+                    }
                 }
             }
         };
@@ -1002,7 +1021,7 @@ __global__ __launch_bounds__(64) void code_pattern_fwd_sweep_kernel(
         for (int r = K; r < NRG; ++r) row_step(r, std::false_type{});
 #pragma unroll
         for (int o = 0; o < R; ++o)
-            if (lay[o] == l) res[o] = acc[o];
+            if (lay[o] == l) res[o] = PK ? acc2[o].x + acc2[o].y : acc[o];
     }
 
     unsigned long long key = 0;
@@ -1038,6 +1057,7 @@ __global__ __launch_bounds__(64) void code_pattern_bwd_sweep_kernel(
     float* __restrict__ partial, float* __restrict__ g_pat0) {
     using S = Sweep<K, R, CW>;
     constexpr int PAD = S::PAD, LW = S::LW, LW0 = S::LW0, LWB = S::LWB, NR = S::NR, NG = S::NG, NRG = R + K - 1;
+    constexpr bool PK = S::PK_BWD;
     constexpr int HB = K - 1 - PAD;               // halo rows / columns before the tile
     extern __shared__ float smem[];
     float* gt = smem;                                              // [NR][LW] gradient / (max + eps), 0 where masked
@@ -1080,9 +1100,13 @@ __global__ __launch_bounds__(64) void code_pattern_bwd_sweep_kernel(
     if (lane == 0) partial[((long)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = sgo;
     __syncthreads();
 
-    float acc[R];
+    float acc[R];                                                 // one of the two sets is used, per PK
+    f2 acc2[R];
 #pragma unroll
-    for (int o = 0; o < R; ++o) acc[o] = 0.0f;
+    for (int o = 0; o < R; ++o) {
+        acc[o] = 0.0f;
+        acc2[o] = f2{0.0f, 0.0f};
+    }
     const float* mine = mt + grp * R * LW + col;                  // this lane's window: rows grp*R .., columns col ..
     for (int l = 0; l < L; ++l) {
         if (__builtin_amdgcn_readfirstlane((int)present[l]) == 0) continue;
@@ -1111,8 +1135,15 @@ __global__ __launch_bounds__(64) void code_pattern_bwd_sweep_kernel(
                 const int d = r - o;
                 if (FULL || (d >= 0 && d < K)) {
                     const float* wr = wbase + o * K;
+                    if (PK) {
 #pragma unroll
-                    for (int e = 0; e < K; ++e) acc[o] = fmaf(wr[K - 1 - e], in[e], acc[o]);
+                        for (int e = 0; e + 1 < K; e += 2)
+                            acc2[o] = __builtin_elementwise_fma(f2{wr[K - 1 - e], wr[K - 2 - e]}, f2{in[e], in[e + 1]}, acc2[o]);
+                        acc2[o].x = fmaf(wr[0], in[K - 1], acc2[o].x);    // K is odd
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < K; ++e) acc[o] = fmaf(wr[K - 1 - e], in[e], acc[o]);
+                    }
                 }
             }
         };
@@ -1123,7 +1154,7 @@ __global__ __launch_bounds__(64) void code_pattern_bwd_sweep_kernel(
 #pragma unroll
     for (int o = 0; o < R; ++o) {
         const int y = yg + o;
-        if (y < H && x < W) st_at(g_pat0 + img, (unsigned)(y * W + x), acc[o]);
+        if (y < H && x < W) st_at(g_pat0 + img, (unsigned)(y * W + x), PK ? acc2[o].x + acc2[o].y : acc[o]);
     }
 }
 
