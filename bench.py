@@ -49,6 +49,7 @@ ALG_BYTES = {
     "code_pattern_bwd_max": 0,        # footprint of the per-image maximum: K*K pixels per image
 }
 assert sum(ALG_BYTES.values()) == 100
+FP32_VECTOR_PEAK = 157.3e12          # flop/s, MI355X fp32 vector (packed FMA) peak
 
 
 def parse():
@@ -282,7 +283,13 @@ def main():
                          "measured_copy_GBps": copy_bandwidth(device) / 1e9,
                          "path_alg_bytes_per_capture": 100 * H * W,
                          "path_frac_per_gpu": (value / world) * 100 * H * W / HBM_PEAK,
-                         "gpu_kernel_us_per_step": gpu_sum_us},
+                         "gpu_kernel_us_per_step": gpu_sum_us,
+                         # the PSF stage's arithmetic (4 K^2 + 120 flop per pixel, forward + backward) against the
+                         # fp32 vector peak: what bounds the step once the PSFs are large
+                         "valu": {"alg_flops_per_capture": (4 * cfg["K"] ** 2 + 120) * H * W,
+                                  "achieved_TFLOPs": (value / world) * (4 * cfg["K"] ** 2 + 120) * H * W / 1e12,
+                                  "peak_TFLOPs": FP32_VECTOR_PEAK / 1e12,
+                                  "frac": (value / world) * (4 * cfg["K"] ** 2 + 120) * H * W / FP32_VECTOR_PEAK}},
             "kernels": {k: {"avg_us": round(v["avg_us"], 2), "launches_per_step": v["launches"] / args.steps,
                             "alg_GBps": round(v["alg_bytes_per_launch"] / (v["avg_us"] * 1e-6) / 1e9, 1)}
                         for k, v in kern.items()},
