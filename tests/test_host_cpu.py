@@ -102,6 +102,17 @@ def test_dropin_module_surface(golden):
         O.codePattern(torch.zeros(1, 8, 8, 21), torch.ones(1, 8, 8, 1))
     with pytest.raises(UnboundLocalError):
         G.gen_visible_mask(torch.zeros(1, 2, 2, 2), "nearest")
+    # the kernels around the path refuse host tensors just as loudly (no silent tensor-op stand-in)
+    from fc3d import ops
+    one, img = torch.ones(1, 8, 8, 1), torch.rand(1, 8, 8, 1)
+    eye = torch.eye(4).unsqueeze(0)
+    for call in (lambda: ops.reflectance(img, one),
+                 lambda: ops.box_filter(img, 5, "mean"),
+                 lambda: ops.capture_post(img, torch.rand(1), img, torch.rand(1), torch.zeros(1, 8, 8, dtype=torch.uint8)),
+                 lambda: ops.capture_warp(img, one, one, torch.rand(8), torch.rand(8), eye, eye),
+                 lambda: ops.ReprojLossFn.apply(one, one, torch.rand(1, 8, 8, 2), eye, eye, img, img, one)):
+        with pytest.raises(RuntimeError, match="GPU only"):
+            call()
 
 
 def test_producers_and_postprocessing_match_reference_fixture(golden):
