@@ -123,7 +123,10 @@ def forward_model(z_p, z_c, pose_p2c, n_layers=21, is_conv_psf=True, crop=None, 
         from . import ops
         rx, ry = G._separable_rays(W, H, dev)
         Ip0 = Ip if Ip.shape[3] == 1 else Ip[..., 0:1]          # codePattern reads channel 0 only
-        Ip_coded = O.codePattern(ops.reflectance(Ip0, z_p), z_p, is_conv_psf=is_conv_psf, n_layers=n_layers)
+        if is_conv_psf:
+            Ip_coded = O.codePattern(ops.reflectance(Ip0, z_p), z_p, is_conv_psf=True, n_layers=n_layers)
+        else:                                                   # the training mode: shading and gating in one pass
+            Ip_coded = ops.code_pattern_shaded(Ip0, z_p, O._layer_grid(n_layers))
         # the launch that forms the two transforms also clears the visibility mask for the splat
         mask = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
         T_p2c, T_c2p, _ = ops.pose_transforms(pose_p2c.detach(), G._intrinsics_for(B, dev), want_fwd=True, want_inv=True,

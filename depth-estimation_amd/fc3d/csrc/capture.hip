@@ -15,17 +15,6 @@
 
 namespace fc3d {
 
-// I * (0.8 cos(atan(|grad z| / 100 um)) + 0.2) with forward differences that are zero on the last
-// row / column.  cos(atan(t)) is evaluated as 1/sqrt(1 + t^2): the same function without the two
-// transcendental roundings (result within 1e-6 relative of the composed form).
-__device__ __forceinline__ float shade(float I, float z0, float zr, float zb, bool has_r, bool has_b) {
-    const float dx = has_r ? __fsub_rn(zr, z0) : 0.0f;
-    const float dy = has_b ? __fsub_rn(zb, z0) : 0.0f;
-    const float t = sqrtf(__fadd_rn(__fmul_rn(dy, dy), __fmul_rn(dx, dx))) / 100e-6f;
-    const float c = 1.0f / sqrtf(__fadd_rn(1.0f, __fmul_rn(t, t)));
-    return __fmul_rn(I, __fadd_rn(__fmul_rn(c, 0.8f), 0.2f));
-}
-
 // VEC = 4 (W divisible by 4, 16-byte aligned planes): four pixels of a row per lane, the row below as a
 // second 16-byte load and the right neighbour of the last pixel from the next lane (one extra load
 // only where the next lane is not the next group of the same row).

@@ -741,7 +741,11 @@ __device__ __forceinline__ int flat_layer(float z, const fc3d_layer_grid& lg, co
     return l;
 }
 
-template <bool VEC>
+// SHADE: the pattern is first multiplied by the surface-slope shading of the same depth map
+// (withReflectance, utils_pytorch.py:251-280, then codePattern: what the reference's training loop
+// does, train_pytorch.py:91-94) -- one more 16-byte load per group for the row below and the
+// right neighbour of a group's last pixel from the next lane.
+template <bool VEC, bool SHADE>
 __global__ __launch_bounds__(NT) void code_pattern_flat_fwd_kernel(
     const float* __restrict__ pat0, long sb, long sh, long sw, const float* __restrict__ z, int H, int W,
     fc3d_layer_grid lg, float* __restrict__ raw, uint8_t* __restrict__ layer_u8,
@@ -758,20 +762,37 @@ __global__ __launch_bounds__(NT) void code_pattern_flat_fwd_kernel(
     const LayerFast lf = layer_fast_setup(lg);
     unsigned long long key = 0;
     if (VEC) {
-        float4 pv[FLAT_GROUPS], zv[FLAT_GROUPS];
+        float4 pv[FLAT_GROUPS], zv[FLAT_GROUPS], zb[FLAT_GROUPS];
+        float zn[FLAT_GROUPS];
 #pragma unroll
         for (int g = 0; g < FLAT_GROUPS; ++g) {
             const unsigned q = min(q0 + g * 256u + lane * 4u, HW - 4u);    // clamped: always a valid group
             pv[g] = ld_at(reinterpret_cast<const float4*>(pimg), q >> 2);
             zv[g] = ld_at(reinterpret_cast<const float4*>(zimg), q >> 2);
+            if (SHADE) {
+                zb[g] = ld_at(reinterpret_cast<const float4*>(zimg), min(q + (unsigned)W, HW - 4u) >> 2);
+                zn[g] = ld_at(zimg, min(q + 4u, HW - 1u));    // only lane 63 uses it; the others take the next lane's
+            }
         }
 #pragma unroll
         for (int g = 0; g < FLAT_GROUPS; ++g) {
             const unsigned q = q0 + g * 256u + lane * 4u;
+            float znext = 0.0f;
+            if (SHADE) {                                       // before the range test: every lane takes part
+                znext = __shfl_down(zv[g].x, 1, 64);
+                if (lane == 63) znext = zn[g];
+            }
             if (q >= HW) continue;
             const unsigned y = q / (unsigned)W, x = q - y * (unsigned)W;   // W % 4 == 0: the group stays in one row
             const float zz[4] = {zv[g].x, zv[g].y, zv[g].z, zv[g].w};
-            const float pp[4] = {pv[g].x, pv[g].y, pv[g].z, pv[g].w};
+            float pp[4] = {pv[g].x, pv[g].y, pv[g].z, pv[g].w};
+            if (SHADE) {
+                const bool has_b = y + 1 < (unsigned)H, has_r = x + 4 < (unsigned)W;
+                pp[0] = shade(pp[0], zz[0], zz[1], zb[g].x, true, has_b);
+                pp[1] = shade(pp[1], zz[1], zz[2], zb[g].y, true, has_b);
+                pp[2] = shade(pp[2], zz[2], zz[3], zb[g].z, true, has_b);
+                pp[3] = shade(pp[3], zz[3], znext, zb[g].w, has_r, has_b);
+            }
             float a[4];
             uint8_t lb[4];
 #pragma unroll
@@ -791,8 +812,14 @@ __global__ __launch_bounds__(NT) void code_pattern_flat_fwd_kernel(
             const unsigned q = q0 + i * 64u + lane;
             if (q >= HW) break;
             const unsigned y = q / (unsigned)W, x = q - y * (unsigned)W;
-            const int l = flat_layer(zimg[q], lg, lf);
-            const float a = pimg[(long)y * sh + (long)x * sw] * (l >= 0 ? 1.0f : 0.0f);
+            const float z0 = zimg[q];
+            const int l = flat_layer(z0, lg, lf);
+            float pq = pimg[(long)y * sh + (long)x * sw];
+            if (SHADE) {
+                const bool has_r = x + 1 < (unsigned)W, has_b = y + 1 < (unsigned)H;
+                pq = shade(pq, z0, has_r ? zimg[q + 1] : z0, has_b ? zimg[q + W] : z0, has_r, has_b);
+            }
+            const float a = pq * (l >= 0 ? 1.0f : 0.0f);
             const uint32_t pos = 0xffffffffu - (uint32_t)(x * (unsigned)H + y);
             const unsigned long long k = ((unsigned long long)float_to_key(a) << 32) | pos;
             key = k > key ? k : key;
@@ -1243,8 +1270,8 @@ extern "C" int fc3d_code_pattern_fwd(void* stream, const float* pat0, int64_t pa
         const bool fvec = HW % 4 == 0 && W % 4 == 0 && HW >= 4 && pat_sw == 1 && pat_sh == W && pat_sb % 4 == 0 &&
                           aligned16(pat0) && aligned16(z) && aligned16(raw_out) && (!layer_u8 || aligned4(layer_u8));
         *keys_per_image = (int)(gf.x * (NT / 64));
-        if (fvec) FC3D_LAUNCH("code_pattern_fwd", code_pattern_flat_fwd_kernel<true>, gf, blk, 0, s, pat0, (long)pat_sb, (long)pat_sh, (long)pat_sw, z, H, W, grid, raw_out, layer_u8, (unsigned long long*)tilekey_u64);
-        else FC3D_LAUNCH("code_pattern_fwd", code_pattern_flat_fwd_kernel<false>, gf, blk, 0, s, pat0, (long)pat_sb, (long)pat_sh, (long)pat_sw, z, H, W, grid, raw_out, layer_u8, (unsigned long long*)tilekey_u64);
+        if (fvec) FC3D_LAUNCH("code_pattern_fwd", (code_pattern_flat_fwd_kernel<true, false>), gf, blk, 0, s, pat0, (long)pat_sb, (long)pat_sh, (long)pat_sw, z, H, W, grid, raw_out, layer_u8, (unsigned long long*)tilekey_u64);
+        else FC3D_LAUNCH("code_pattern_fwd", (code_pattern_flat_fwd_kernel<false, false>), gf, blk, 0, s, pat0, (long)pat_sb, (long)pat_sh, (long)pat_sw, z, H, W, grid, raw_out, layer_u8, (unsigned long long*)tilekey_u64);
         return FC3D_OK;
     }
     if (conv_flag && Kh == Kw && fits32) {
@@ -1280,6 +1307,25 @@ extern "C" int fc3d_code_pattern_fwd(void* stream, const float* pat0, int64_t pa
     *keys_per_image = (int)(g.x * g.y);
     FC3D_LAUNCH("code_pattern_fwd", k, g, blk, lds, s, pat0, (long)pat_sb, (long)pat_sh, (long)pat_sw, z, psf, H, W, Kh,
                 Kw, conv_flag, cap, grid, raw_out, layer_u8, (unsigned long long*)tilekey_u64);
+    return FC3D_OK;
+}
+
+extern "C" int fc3d_code_pattern_shaded_fwd(void* stream, const float* pat0, int64_t pat_sb, int64_t pat_sh,
+                                            int64_t pat_sw, const float* z, int B, int H, int W, fc3d_layer_grid grid,
+                                            float* raw_out, uint8_t* layer_u8, uint64_t* tilekey_u64,
+                                            int* keys_per_image) {
+    if (!pat0 || !z || !raw_out || !tilekey_u64 || !keys_per_image || B <= 0 || H <= 0 || W <= 0) return FC3D_EINVAL;
+    if (grid.n_layers <= 0 || grid.n_layers > 254) return FC3D_EINVAL;
+    const long HW = (long)H * W;
+    if ((long)B * HW >= (1L << 31) || B > 65535 || HW >= (1L << 30)) return FC3D_ERANGE;
+    if (!aligned4(pat0) || !aligned4(z) || !aligned4(raw_out)) return FC3D_EALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 gf(cdiv(cdiv(HW, FLAT_WAVE_PX), NT / 64), B), blk(NT);
+    const bool fvec = HW % 4 == 0 && W % 4 == 0 && HW >= 4 && pat_sw == 1 && pat_sh == W && pat_sb % 4 == 0 &&
+                      aligned16(pat0) && aligned16(z) && aligned16(raw_out) && (!layer_u8 || aligned4(layer_u8));
+    *keys_per_image = (int)(gf.x * (NT / 64));
+    if (fvec) FC3D_LAUNCH("code_pattern_shaded_fwd", (code_pattern_flat_fwd_kernel<true, true>), gf, blk, 0, s, pat0, (long)pat_sb, (long)pat_sh, (long)pat_sw, z, H, W, grid, raw_out, layer_u8, (unsigned long long*)tilekey_u64);
+    else FC3D_LAUNCH("code_pattern_shaded_fwd", (code_pattern_flat_fwd_kernel<false, true>), gf, blk, 0, s, pat0, (long)pat_sb, (long)pat_sh, (long)pat_sw, z, H, W, grid, raw_out, layer_u8, (unsigned long long*)tilekey_u64);
     return FC3D_OK;
 }
 

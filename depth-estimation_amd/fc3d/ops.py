@@ -503,6 +503,32 @@ def _plane(t: torch.Tensor, B: int, H: int, W: int, what: str) -> torch.Tensor:
     return _dense(t)
 
 
+def code_pattern_shaded(I: torch.Tensor, z: torch.Tensor, grid: LayerGrid) -> torch.Tensor:
+    """codePattern(withReflectance(I, z), z, is_conv_psf=False) in one streaming pass plus the
+    normalisation: the pattern path of the reference's training loop.  I [B or 1,H,W,1] (channel 0
+    of the pattern), z [B,H,W,1] -> [B,H,W,1]; no gradient."""
+    dev = _need_gpu(I, z)
+    B, H, W = z.shape[0], z.shape[1], z.shape[2]
+    if I.dim() != 4 or I.shape[3] != 1 or I.shape[0] not in (1, B) or tuple(I.shape[1:3]) != (H, W):
+        raise ValueError(f"pattern of shape {tuple(I.shape)} does not match depth {tuple(z.shape)}")
+    I = I.detach()
+    zd = _plane(z.detach(), B, H, W, "z")
+    sb = I.stride(0) if I.shape[0] == B and B > 1 else 0
+    out = torch.empty((B, H, W, 1), dtype=torch.float32, device=dev)
+    keys = torch.empty(_lib.fc3d_code_pattern_fwd_workspace(B, H, W) // 8, dtype=torch.int64, device=dev)
+    mx = torch.empty(B, dtype=torch.float32, device=dev)
+    am = torch.empty(B, dtype=torch.int32, device=dev)
+    nkeys = ctypes.c_int(0)
+    with _on_device(dev):
+        s = _stream()
+        _check(_lib.fc3d_code_pattern_shaded_fwd(s, I.data_ptr(), sb, I.stride(1), I.stride(2), zd.data_ptr(), B, H, W,
+                                                 grid, out.data_ptr(), None, keys.data_ptr(), ctypes.byref(nkeys)),
+               "fc3d_code_pattern_shaded_fwd")
+        _check(_lib.fc3d_code_pattern_norm(s, out.data_ptr(), keys.data_ptr(), nkeys.value, B, H, W, out.data_ptr(),
+                                           mx.data_ptr(), am.data_ptr()), "fc3d_code_pattern_norm")
+    return out
+
+
 def reflectance(I: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
     """I [B or 1,H,W,1] * (0.8 cos(atan(|grad z| / 100um)) + 0.2), z [B,H,W,1]; no gradient."""
     dev = _need_gpu(I, z)

@@ -80,6 +80,17 @@ int fc3d_code_pattern_fwd(void *stream, const float *pat0, int64_t pat_sb, int64
                           float *raw_out, uint8_t *layer_u8, uint64_t *tilekey_u64,
                           int *keys_per_image /* HOST, out: keys written per image; pass to _norm */);
 
+/* withReflectance (utils_pytorch.py:251-280) followed by the first half of codePattern without
+ * blur (optics_pytorch.py:110-112) in one pass -- train_pytorch.py:91-94 as the reference's training
+ * loop runs it (is_conv_psf=False, :51-52):  raw = pattern0 * (0.8 cos(atan(|grad z|/100e-6)) + 0.2)
+ * where z falls into a layer, 0 elsewhere.  Same arguments and outputs as fc3d_code_pattern_fwd
+ * (follow with fc3d_code_pattern_norm); identical to fc3d_reflectance_fwd + fc3d_code_pattern_fwd
+ * with conv_flag 0 on the same inputs.  No backward: the reference runs it without gradients.   */
+int fc3d_code_pattern_shaded_fwd(void *stream, const float *pat0, int64_t pat_sb, int64_t pat_sh, int64_t pat_sw,
+                                 const float *z, int B, int H, int W, fc3d_layer_grid grid, float *raw_out,
+                                 uint8_t *layer_u8, uint64_t *tilekey_u64,
+                                 int *keys_per_image /* HOST, out */);
+
 /* Forward, second half: out = raw / (max + 1e-10) per image, in place allowed
  * (optics_pytorch.py:118-119).  Also unpacks max_out[B] and argmax_i32[B]
  * (flat y*W+x of the pixel that receives the max's gradient).                 */

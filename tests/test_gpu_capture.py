@@ -115,6 +115,10 @@ def test_capture_kernels_match_composed_operators(env, monkeypatch, B, H, W):
         assert got.shape == want.shape
         assert rel_err(got.cpu().numpy(), want.cpu().numpy()) < 1e-5
 
+        # ... and fused with the no-blur codePattern (the training mode): identical to the two steps
+        one = env["O"].codePattern(got, z_p, is_conv_psf=False, n_layers=21)
+        assert torch.equal(ops.code_pattern_shaded(pat, z_p, env["O"]._layer_grid(21)), one)
+
     # warp from the depth maps
     rays = G.pixel_to_ray_array(W, H)
     coord_p = G.points_in_camera_coords(z_p, rays).permute(0, 3, 1, 2)
