@@ -255,7 +255,8 @@ __global__ __launch_bounds__(NT) void bilinear_bwd_grid_kernel(const float* __re
 // ---------------------------------------------------------------------------------------
 // d out / d img for C == 1: scatter-add through per-wavefront LDS windows
 //
-// Scatter: each wavefront owns a 32x8 tile of target pixels.  It finds the bounding box of the
+// Scatter: each wavefront owns a 32x8 tile of target pixels (four neighbouring pixels of a row
+//   per lane).  It finds the bounding box of the
 //   source pixels its taps touch (DPP min/max) and sums all taps into a private LDS window of
 //   that box.  LDS float atomics retire about one lane every three cycles on this chip, so the
 //   window is updated with plain read-add-write; lanes of one instruction that hit the same cell
@@ -272,7 +273,11 @@ __global__ __launch_bounds__(NT) void bilinear_bwd_grid_kernel(const float* __re
 // A sample whose two x corners (or two y corners) were clamped onto the same source pixel
 // contributes +w and -w to that pixel, i.e. exactly nothing; such samples are skipped.
 // ---------------------------------------------------------------------------------------
-constexpr int WT_X = 32, WT_Y = 8;       // wavefront tile
+// Wavefront tile: 8 lanes x 4 neighbouring pixels in each of 8 rows.  (64 x 4 loads a little faster
+// still -- 56.8 against 58 us at 32x512x512 -- but its box under a 20 degree rotation no longer fits
+// the window and the kernel falls from 39 to 85 us there.)
+constexpr int WT_X = 32, WT_Y = 8;
+constexpr int WT_LX = WT_X / 4;          // lanes along x
 constexpr int WIN_CAP = 1024;            // cells per window / floats per slab
 
 struct TileMeta { int xmin, ymin, ww, wh; };   // ww = 0: empty, ww = -1: overflow
@@ -313,9 +318,8 @@ __device__ __forceinline__ int wave_max_dpp(int v) {
 __device__ __forceinline__ void load_tile_taps(const float* __restrict__ g_out, const float* __restrict__ grid,
                                                const uint8_t* __restrict__ mask_u8, long tb, int Ht, int Wt, int Hs,
                                                int Ws, int tx0, int ty0, int lane, PxTaps px[4]) {
-    // all twelve loads up front, unconditionally, from clamped (always valid) positions: one
-    // memory latency per tile; a load inside an `if` would cost one each
-    const int x = tx0 + (lane & 31);
+    // all loads up front, unconditionally, from clamped (always valid) positions: one memory
+    // latency per tile; a load inside an `if` would cost one each
     const float2* gb = reinterpret_cast<const float2*>(grid) + tb;
     const float* vb = g_out + tb;
     const uint8_t* mb = mask_u8 ? mask_u8 + tb : nullptr;
@@ -323,14 +327,36 @@ __device__ __forceinline__ void load_tile_taps(const float* __restrict__ g_out, 
     float gv[4];
     uint8_t mk[4];
     bool vis[4];
+    {
+        // a lane owns four neighbouring pixels of one row: one 16-byte load of g, two of the grid, one
+        // 4-byte load of the mask (measured against one pixel per lane and load: 58 instead of 64 us
+        // for the whole kernel at 32x512x512)
+        const int x = tx0 + 4 * (lane % WT_LX), y = ty0 + lane / WT_LX;
+        const bool vec = (Wt % 4 == 0) && ((reinterpret_cast<uintptr_t>(g_out) | reinterpret_cast<uintptr_t>(grid)) % 16 == 0) &&
+                         (!mask_u8 || reinterpret_cast<uintptr_t>(mask_u8) % 4 == 0);
+        if (vec) {
+            const unsigned q = (unsigned)(min(y, Ht - 1) * Wt + min(x, Wt - 4));
+            const float4 a = ld_at(reinterpret_cast<const float4*>(vb), q >> 2);
+            const float4 g0 = ld_at(reinterpret_cast<const float4*>(gb), q >> 1);
+            const float4 g1 = ld_at(reinterpret_cast<const float4*>(gb), (q >> 1) + 1);
+            uchar4 m4 = make_uchar4(1, 1, 1, 1);
+            if (mb) m4 = ld_at(reinterpret_cast<const uchar4*>(mb), q >> 2);
+            gv[0] = a.x; gv[1] = a.y; gv[2] = a.z; gv[3] = a.w;
+            g[0] = make_float2(g0.x, g0.y); g[1] = make_float2(g0.z, g0.w);
+            g[2] = make_float2(g1.x, g1.y); g[3] = make_float2(g1.z, g1.w);
+            mk[0] = m4.x; mk[1] = m4.y; mk[2] = m4.z; mk[3] = m4.w;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int y = ty0 + (lane >> 5) + 2 * k;
-        vis[k] = (x < Wt) && (y < Ht);
-        const unsigned q = (unsigned)(min(y, Ht - 1) * Wt + min(x, Wt - 1));
-        g[k] = ld_at(gb, q);
-        gv[k] = ld_at(vb, q);
-        mk[k] = mb ? ld_at(mb, q) : (uint8_t)1;
+            for (int k = 0; k < 4; ++k) vis[k] = (x + k < Wt) && (y < Ht);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                vis[k] = (x + k < Wt) && (y < Ht);
+                const unsigned q = (unsigned)(min(y, Ht - 1) * Wt + min(x + k, Wt - 1));
+                g[k] = ld_at(gb, q);
+                gv[k] = ld_at(vb, q);
+                mk[k] = mb ? ld_at(mb, q) : (uint8_t)1;
+            }
+        }
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
