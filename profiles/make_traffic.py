@@ -50,7 +50,8 @@ def bench_name(sym):
 
 
 def counters(d):
-    f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    f = sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True),
+               key=os.path.getmtime, reverse=True)        # the latest run under this tag
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     if not f:
         return agg
@@ -69,7 +70,8 @@ def main():
     a = ap.parse_args()
     out = os.path.join(ROOT, "profiles")
     src = os.path.join(ROOT, "gpurun_out")
-    st = glob.glob(os.path.join(src, a.tag + "_stats", "**", "*kernel_stats.csv"), recursive=True)
+    st = sorted(glob.glob(os.path.join(src, a.tag + "_stats", "**", "*kernel_stats.csv"), recursive=True),
+                key=os.path.getmtime, reverse=True)
     if st:
         shutil.copy(st[0], os.path.join(out, a.tag + "_kernel_stats.csv"))
     fe = counters(os.path.join(src, a.tag + "_pmc_fetch"))
