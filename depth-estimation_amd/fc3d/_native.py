@@ -49,6 +49,7 @@ SIGNATURES = {
     "fc3d_reproject_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "fc3d_reproj_loss_workspace": (c_size_t, [c_int, c_int, c_int]),
     "fc3d_reproj_loss_fwd": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
+    "fc3d_reproj_loss_fwd_static": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
     "fc3d_reproj_loss_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "fc3d_zp_to_zc_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
     "fc3d_zp_to_zc_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),

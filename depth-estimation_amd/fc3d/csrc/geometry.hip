@@ -8,6 +8,7 @@
 // the operation order of the reference's tensor ops exactly; explicit __fmul_rn/__fadd_rn
 // and fmaf keep the compiler from re-associating or contracting it.
 #include "geom_dev.h"
+#include <atomic>
 
 namespace fc3d {
 
@@ -1264,6 +1265,50 @@ extern "C" int fc3d_reproj_loss_fwd(void* stream, const float* zp_hat, const flo
     return FC3D_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// fc3d_reproj_loss_fwd without a workspace argument: the per-workgroup partial sums live in a
+// file-scope device array instead, so the call needs no device memory beyond its inputs and
+// outputs.  Every GPU holds its own copy of the array at its own address; the address is looked
+// up once per device (with that device current) and kept.  `scratch` below is only the host-side
+// handle of the symbol: kernels and copies always get the looked-up device address.
+// ---------------------------------------------------------------------------------------
+constexpr long kScratchPartials = 65536;           // float4 partial sums: 1 MiB per GPU
+static __device__ __align__(256) float4 scratch[kScratchPartials];
+constexpr int kScratchMaxDevices = 64;
+static std::atomic<float4*> s_scratch_ptr[kScratchMaxDevices];
+
+static int scratch_for_current_device(float4** out) {
+    int dev = -1;
+    FC3D_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kScratchMaxDevices) return FC3D_ERANGE;
+    float4* p = s_scratch_ptr[dev].load(std::memory_order_acquire);
+    if (!p) {
+        FC3D_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(scratch)));
+        if (!p) return FC3D_EINVAL;
+        s_scratch_ptr[dev].store(p, std::memory_order_release);   // racing first calls look up the same address
+    }
+    *out = p;
+    return FC3D_OK;
+}
+
+extern "C" int fc3d_reproj_loss_fwd_static(void* stream, const float* zp_hat, const float* mask, const float* xy,
+                                           const float* inv, const float* T, const float* img, const float* Ic,
+                                           const float* zcGT, int B, int H, int W, int Hs, int Ws, float* sums,
+                                           float* losses) {
+    if (!zp_hat || !mask || !xy || !inv || !T || !img || !Ic || !zcGT || !sums || !losses) return FC3D_EINVAL;
+    if (int e = check_reproject(xy, B, H, W, Hs, Ws)) return e;
+    const dim3 g(cdiv((long)H * W, NT), B), blk(NT);
+    if ((long)g.x * B > kScratchPartials) return FC3D_ESCRATCH;
+    float4* partial = nullptr;
+    if (int e = scratch_for_current_device(&partial)) return e;
+    hipStream_t s = (hipStream_t)stream;
+    // every partial the sum reads is written by the first launch: nothing has to start at zero
+    if (use_fma(H, W)) FC3D_LAUNCH("reproj_loss_fwd", reproj_loss_fwd_kernel<true>, g, blk, 0, s, zp_hat, mask, xy, inv, T, img, Ic, zcGT, H, W, Hs, Ws, partial);
+    else FC3D_LAUNCH("reproj_loss_fwd", reproj_loss_fwd_kernel<false>, g, blk, 0, s, zp_hat, mask, xy, inv, T, img, Ic, zcGT, H, W, Hs, Ws, partial);
+    FC3D_LAUNCH("reproj_loss_sum", reproj_loss_sum_kernel, dim3(1), blk, 0, s, (const float4*)partial, (long)g.x * B, sums, losses);
+    return FC3D_OK;
+}
+
 extern "C" int fc3d_reproj_loss_bwd(void* stream, const float* g_losses, const float* sums, const float* zp_hat,
                                     const float* mask,
                                     const float* xy, const float* inv, const float* T, const float* img,
@@ -1286,6 +1331,7 @@ extern "C" const char* fc3d_status_string(int status) {
         case FC3D_EINVAL: return "invalid argument (null pointer or non-positive size)";
         case FC3D_ERANGE: return "size out of the range the kernels index";
         case FC3D_EALIGN: return "pointer not aligned to its element type";
+        case FC3D_ESCRATCH: return "problem larger than the library's static scratch buffer (fc3d_reproj_loss_fwd_static: B*ceil(H*W/256) <= 65536)";
         default: break;
     }
     if (status > 0) return hipGetErrorString((hipError_t)status);

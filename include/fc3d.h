@@ -34,6 +34,7 @@ extern "C" {
 #define FC3D_EINVAL (-1)     /* null pointer / non-positive size */
 #define FC3D_ERANGE (-2)     /* size beyond what the kernels index (e.g. B*H*W >= 2^31) */
 #define FC3D_EALIGN (-3)     /* pointer not aligned to its element type */
+#define FC3D_ESCRATCH (-4)   /* problem larger than the library's static scratch buffer */
 
 #define FC3D_VERSION 100
 
@@ -224,6 +225,20 @@ int fc3d_reproj_loss_fwd(void *stream, const float *zp_hat, const float *mask, c
 int fc3d_reproj_loss_bwd(void *stream, const float *g_losses, const float *sums, const float *zp_hat,
                          const float *mask, const float *xy, const float *inv, const float *T, const float *img,
                          const float *Ic, const float *zcGT, int B, int H, int W, int Hs, int Ws, float *g_zp_hat);
+
+/* fc3d_reproj_loss_fwd for callers that cannot allocate or pass device memory beyond inputs and
+ * outputs (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).
+ * It has no counterpart in the reference.  Same arguments, kernels and results as
+ * fc3d_reproj_loss_fwd, minus the workspace: the partial sums go to a 1 MiB array that is part of
+ * the library's code object on every GPU (looked up once per device, on the first call made with
+ * that device current; the call never allocates or frees).  Limit: B * ceil(H*W/256) <= 65536
+ * partial sums (e.g. 64 images of 512x512), otherwise FC3D_ESCRATCH and nothing is launched.
+ * All calls on one GPU share that array: calls whose kernels may overlap on one GPU (different
+ * streams, or several host threads) race on it and must be serialised by the caller.          */
+int fc3d_reproj_loss_fwd_static(void *stream, const float *zp_hat, const float *mask, const float *xy,
+                                const float *inv, const float *T, const float *img, const float *Ic,
+                                const float *zcGT, int B, int H, int W, int Hs, int Ws, float *sums,
+                                float *losses);
 
 /* ------------------------------------------------------------------------ */
 /* the capture simulator around the path (forward_model, train_pytorch.py:     */

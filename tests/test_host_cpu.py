@@ -44,6 +44,10 @@ def test_cabi_exports_every_declared_symbol():
     assert lib.fc3d_capture_warp_fwd(None, one, one, one, one, one, one, one, 1, 8, 8, one, None, one, 0, None, None) == -1
     assert lib.fc3d_reflectance_fwd(None, one, -1, one, 1, 8, 8, one) == -1            # negative batch stride
     assert lib.fc3d_reproj_loss_fwd(None, one, one, None, one, one, one, one, one, 1, 8, 8, 8, 8, one, one, one) == -1
+    assert lib.fc3d_reproj_loss_fwd_static(None, one, one, None, one, one, one, one, one, 1, 8, 8, 8, 8, one, one) == -1
+    # more partial sums than the library's static array holds: refused before any device work
+    assert lib.fc3d_reproj_loss_fwd_static(None, one, one, one, one, one, one, one, one, 300, 512, 512, 512, 512,
+                                           one, one) == -4
 
 
 def test_layer_grid_matches_reference_tables(golden):
