@@ -41,14 +41,15 @@ ALG_BYTES = {
     "pose_transforms": 0,
     "warp_project_splat": 24,         # coord_p 16 -> grid_p2c 8 (mask is internal)
     "warp_sample": 32,                # Ip 4 + coord_c 16 -> Ic 4 + grid_c2p 8
-    "bilinear_bwd_img_scatter": 16,   # dL/dIc 4 + grid_c2p 8 -> dL/dIp 4 (window sums added with atomics)
-    "bilinear_bwd_img_merge": 0,      # only in torch's deterministic mode (fixed-order merge of stored windows)
-    "bilinear_bwd_img_overflow": 0,
+    "bilinear_bwd_img_gather": 16,    # dL/dIc 4 + grid_c2p 8 -> dL/dIp 4 (--bwd ordered: source tiles gather their samples)
+    "bilinear_bwd_img_scatter": 16,   # the same bytes with --bwd atomic (window sums added with float atomics) ...
+    "zero_fill": 0,                   # ... into a gradient image that has to be cleared first
+    "bilinear_tap_index": 0,          # only when the sampler runs outside warp_p2c (which writes the index itself)
     "code_pattern_bwd_reduce": 0,     # only for PSF sizes without a rolling-row kernel
     "code_pattern_bwd": 16,           # dL/dIp 4 + layer(z) 4 + Ip_coded 4 -> dL/dpattern0 4
     "code_pattern_bwd_max": 0,        # footprint of the per-image maximum: K*K pixels per image
 }
-assert sum(ALG_BYTES.values()) == 100
+assert sum(v for k, v in ALG_BYTES.items() if k != "bilinear_bwd_img_scatter") == 100
 FP32_VECTOR_PEAK = 157.3e12          # flop/s, MI355X fp32 vector (packed FMA) peak
 
 
@@ -66,6 +67,9 @@ def parse():
                          "buffers); eager: every launch issued from Python (about 125 us of host time per step; "
                          "at the headline size that hides behind the kernels on a quiet host and is ~2%% faster "
                          "than replay, but one run in three measured 15%% slower, so replay is the default)")
+    ap.add_argument("--bwd", choices=("ordered", "atomic"), default="ordered",
+                    help="gradient of the warp w.r.t. the pattern: ordered = gather form without atomics (fixed "
+                         "summation order), atomic = scatter form with global float atomics")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     return ap.parse_args()
@@ -195,7 +199,8 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=device)
 
-    from fc3d import profiler
+    from fc3d import ops as fc3d_ops, profiler
+    fc3d_ops.set_image_gradient_mode(args.bwd)
     wl, tens = build_inputs(args, rank, device)
     cfg = wl["cfg"]
     B, H, W = cfg["B"], cfg["H"], cfg["W"]
@@ -276,7 +281,7 @@ def main():
                                    f"{cfg['K']}x{cfg['K']} '{args.psf_kind}' PSFs, pose theta<={cfg['theta_deg']}deg; "
                                    "codePattern -> warp_p2c fwd + bwd to pattern[...,0]",
                        "global_batch": world * B, "parallelism": f"batch-sharded x{world}, no collective",
-                       "launch": launch, "replay_matches_eager": replay_ok},
+                       "launch": launch, "replay_matches_eager": replay_ok, "bwd": args.bwd},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
                          "kernel_avg_us": dk["avg_us"], "alg_bytes_per_launch": dk["alg_bytes_per_launch"],

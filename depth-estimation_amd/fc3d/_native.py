@@ -39,10 +39,11 @@ SIGNATURES = {
     "fc3d_bilinear_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "fc3d_bilinear_bwd_grid": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "fc3d_bilinear_bwd_img_workspace": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
-    "fc3d_bilinear_bwd_img": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "fc3d_bilinear_tap_index": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "fc3d_bilinear_bwd_img": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, P]),
     "fc3d_visible_mask": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P]),
     "fc3d_warp_p2c_fwd": (c_int, [P, P, P, I64, I64, I64, I64, P, I64, I64, I64, I64, P, P, c_int, c_int, c_int,
-                                  P, P, P, P, c_int]),
+                                  P, P, P, P, c_int, P]),
     "fc3d_points_fwd": (c_int, [P, P, P, P, P, I64, c_int, c_int, c_int, P]),
     "fc3d_points_bwd": (c_int, [P, P, P, P, P, I64, c_int, c_int, c_int, P]),
     "fc3d_reproject_fwd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
@@ -87,8 +88,8 @@ def load() -> ctypes.CDLL:
             raise ImportError(f"{LIB_PATH} does not export {name}; rebuild it") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.fc3d_version() != 100:
-        raise ImportError(f"{LIB_PATH} reports version {lib.fc3d_version()}, expected 100; rebuild it")
+    if lib.fc3d_version() != 200:
+        raise ImportError(f"{LIB_PATH} reports version {lib.fc3d_version()}, expected 200; rebuild it")
     _lib = lib
     return lib
 

@@ -38,6 +38,19 @@ void prof_after(hipStream_t s);
 
 constexpr int kWave = 64;
 
+// Pointers into LDS that say so in their type.  A plain (generic) pointer to a __shared__ array that
+// the compiler cannot trace back to the array (volatile accesses, pointers held across lambdas) is
+// accessed with flat_load / flat_store: slower than ds_read / ds_write and counted in the vector
+// memory counter too, so that every wait for an LDS value also waits for all global loads in flight.
+#define FC3D_LDS __attribute__((address_space(3)))
+typedef volatile FC3D_LDS float* lds_vfloat;
+typedef volatile FC3D_LDS uint8_t* lds_vu8;
+typedef volatile FC3D_LDS int* lds_vint;
+template <typename T>
+__device__ __forceinline__ volatile FC3D_LDS T* lds_ptr(T* p) {
+    return (volatile FC3D_LDS T*)p;
+}
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline bool aligned4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0; }
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

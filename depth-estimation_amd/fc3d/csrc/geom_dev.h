@@ -113,6 +113,139 @@ __device__ __forceinline__ float blend(const Taps& t, float i00, float i01, floa
     return o;
 }
 
+// ---------------------------------------------------------------------------------------
+// Tap index: where the samples of a grid land in the source image, kept at three levels so that the
+// image-gradient pass of the sampler can find, for a tile of the SOURCE image, every target pixel
+// that may touch it:
+//   segment  SEG consecutive target pixels (one row of 16 lanes),
+//   run      64*PPL consecutive target pixels: what one wavefront of the streaming kernels owns,
+//   group    NT*PPL consecutive target pixels: what one workgroup of them owns.
+// Every level stores one box per unit: the range of the samples' base cells (x0, y0) = (floor x,
+// floor y) after clamping, over the samples that contribute at all (inside the target, mask set,
+// corners not clamped onto each other), packed as two signed 16-bit pairs: lo = (xmin | ymin << 16),
+// hi = (xmax | ymax << 16).  An empty box has min = 32767 and max = -32768 in every field, which
+// fails every overlap test.  The reductions run in the data-parallel-primitive path on packed
+// 16-bit min/max.  A segment's entry is (xmin | ymin << 16, width | height << 8 | live << 16): the
+// box as corner and extent (255 = that much or more) and one bit per pixel of the segment that says
+// whether its sample contributes, so that the gradient pass needs neither the mask nor the clamp
+// tests again.  Layout of the index of one batch: [B][groups] group boxes, [B][groups*RUN_PER_GROUP]
+// run boxes, [B][groups*RUN_PER_GROUP*SEG_PER_RUN] segment boxes.
+// ---------------------------------------------------------------------------------------
+constexpr int SEG = 16;
+constexpr int SEG_PER_RUN = 64 * PPL / SEG;
+constexpr int RUN_PER_GROUP = NT / 64;
+constexpr int kBoxEmptyMin = 0x7fff7fff;
+constexpr int kBoxEmptyMax = (int)0x80008000;
+constexpr int kTapIndexMaxDim = 32767;               // source sizes the 16-bit fields can hold
+
+typedef short short2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int pk_min(int a, int b) {
+    return __builtin_bit_cast(int, __builtin_elementwise_min(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b)));
+}
+__device__ __forceinline__ int pk_max(int a, int b) {
+    return __builtin_bit_cast(int, __builtin_elementwise_max(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b)));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_keep(int old, int src) {   // lanes without a source lane keep `old`
+    return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xf, false);
+}
+// lane 15 of every row of 16 lanes ends with the row's result
+__device__ __forceinline__ int row_pk_min(int v) {
+    v = pk_min(v, dpp_keep<0x111, 0xf>(kBoxEmptyMin, v));   // row_shr:1
+    v = pk_min(v, dpp_keep<0x112, 0xf>(kBoxEmptyMin, v));   // row_shr:2
+    v = pk_min(v, dpp_keep<0x114, 0xf>(kBoxEmptyMin, v));   // row_shr:4
+    v = pk_min(v, dpp_keep<0x118, 0xf>(kBoxEmptyMin, v));   // row_shr:8
+    return v;
+}
+__device__ __forceinline__ int row_pk_max(int v) {
+    v = pk_max(v, dpp_keep<0x111, 0xf>(kBoxEmptyMax, v));
+    v = pk_max(v, dpp_keep<0x112, 0xf>(kBoxEmptyMax, v));
+    v = pk_max(v, dpp_keep<0x114, 0xf>(kBoxEmptyMax, v));
+    v = pk_max(v, dpp_keep<0x118, 0xf>(kBoxEmptyMax, v));
+    return v;
+}
+// from per-row results in lanes 15, 31, 47, 63 to the wavefront's result in lane 63
+__device__ __forceinline__ int rows_pk_min(int v) {
+    v = pk_min(v, dpp_keep<0x142, 0xa>(kBoxEmptyMin, v));   // row_bcast:15 into rows 1, 3
+    v = pk_min(v, dpp_keep<0x143, 0xc>(kBoxEmptyMin, v));   // row_bcast:31 into rows 2, 3
+    return v;
+}
+__device__ __forceinline__ int rows_pk_max(int v) {
+    v = pk_max(v, dpp_keep<0x142, 0xa>(kBoxEmptyMax, v));
+    v = pk_max(v, dpp_keep<0x143, 0xc>(kBoxEmptyMax, v));
+    return v;
+}
+
+__host__ __device__ static inline long tap_index_groups(int Ht, int Wt) {
+    return ((long)Ht * Wt + PX_PER_BLOCK - 1) / PX_PER_BLOCK;
+}
+struct TapIndex {            // the three levels of one image (or, with b = 0, the start of a batch's arrays)
+    int2 *group, *run, *seg;
+};
+__host__ __device__ static inline TapIndex tap_index_at(void* base, int B, long groups, int b) {
+    TapIndex t;
+    int2* p = static_cast<int2*>(base);
+    t.group = p + (long)b * groups;
+    t.run = p + (long)B * groups + (long)b * groups * RUN_PER_GROUP;
+    t.seg = p + (long)B * groups * (1 + RUN_PER_GROUP) + (long)b * groups * RUN_PER_GROUP * SEG_PER_RUN;
+    return t;
+}
+
+// Every thread of a workgroup of the streaming kernels calls this with its PPL samples (pixel
+// lane_first_pixel() + 64*i for slot i; on[i] false for samples that contribute nothing, pixels
+// past the image included).  Writes the boxes of the workgroup's group, runs and segments.
+// Contains a workgroup barrier.
+__device__ __forceinline__ void emit_tap_index(const TapIndex& ix, const int x0[PPL], const int y0[PPL],
+                                               const bool on[PPL]) {
+    __shared__ int2 s_runbox[RUN_PER_GROUP];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long run = (long)blockIdx.x * RUN_PER_GROUP + wv;
+    int wmin = kBoxEmptyMin, wmax = kBoxEmptyMax;
+#pragma unroll
+    for (int i = 0; i < PPL; ++i) {
+        const int pk = x0[i] | (y0[i] << 16);
+        const int mn = row_pk_min(on[i] ? pk : kBoxEmptyMin);
+        const int mx = row_pk_max(on[i] ? pk : kBoxEmptyMax);
+        const unsigned long long live = __ballot(on[i]);
+        if ((lane & 15) == 15) {
+            const unsigned bits = (unsigned)(live >> (lane & 48)) & 0xffffu;
+            const int w = min((short)(mx & 0xffff) - (short)(mn & 0xffff), 255), h = min((mx >> 16) - (mn >> 16), 255);
+            ix.seg[run * SEG_PER_RUN + i * (64 / SEG) + (lane >> 4)] =
+                make_int2(mn, bits ? (int)((unsigned)w | ((unsigned)h << 8) | (bits << 16)) : 0);
+        }
+        wmin = pk_min(wmin, mn);
+        wmax = pk_max(wmax, mx);
+    }
+    wmin = rows_pk_min(wmin);
+    wmax = rows_pk_max(wmax);
+    if (lane == 63) {
+        ix.run[run] = make_int2(wmin, wmax);
+        s_runbox[wv] = make_int2(wmin, wmax);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int gmin = s_runbox[0].x, gmax = s_runbox[0].y;
+#pragma unroll
+        for (int w = 1; w < RUN_PER_GROUP; ++w) {
+            gmin = pk_min(gmin, s_runbox[w].x);
+            gmax = pk_max(gmax, s_runbox[w].y);
+        }
+        ix.group[blockIdx.x] = make_int2(gmin, gmax);
+    }
+}
+
+// does a segment's entry meet the base-cell range [bx0, bx1] x [by0, by1]?
+__device__ __forceinline__ bool seg_meets(int2 m, int bx0, int bx1, int by0, int by1) {
+    const int xmin = (short)(m.x & 0xffff), ymin = m.x >> 16, w = m.y & 0xff, h = (m.y >> 8) & 0xff;
+    return (m.y != 0) && xmin <= bx1 && ymin <= by1 && (w == 255 || xmin + w >= bx0) && (h == 255 || ymin + h >= by0);
+}
+
+// does box (lo, hi) meet the base-cell range [bx0, bx1] x [by0, by1]?
+__device__ __forceinline__ bool box_meets(int2 m, int bx0, int bx1, int by0, int by1) {
+    const int xmin = (short)(m.x & 0xffff), ymin = m.x >> 16, xmax = (short)(m.y & 0xffff), ymax = m.y >> 16;
+    return xmin <= bx1 && xmax >= bx0 && ymin <= by1 && ymax >= by0;
+}
+
 static inline int check_img(int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0) return FC3D_EINVAL;
     if ((long)B * H * W >= (1L << 31) || B > 65535 || H > 65535) return FC3D_ERANGE;

@@ -160,7 +160,8 @@ __global__ __launch_bounds__(NT) void warp_sample_kernel(const float* __restrict
                                                          long sw, const float* __restrict__ Tm,
                                                          const float* __restrict__ Ip,
                                                          const uint8_t* __restrict__ mask_u8, int H, int W,
-                                                         float* __restrict__ grid, float* __restrict__ out) {
+                                                         float* __restrict__ grid, float* __restrict__ out,
+                                                         void* __restrict__ tap_index, int B) {
     const int b = blockIdx.y;
     const long HW = (long)H * W;
     const long p0 = lane_first_pixel();
@@ -201,6 +202,18 @@ __global__ __launch_bounds__(NT) void warp_sample_kernel(const float* __restrict
             go[p] = make_float2(gx[i], gy[i]);
             oo[p] = blend(t[i], i00[i], i01[i], i10[i], i11[i]) * mv[i];
         }
+    }
+    if (tap_index) {   // for the gradient w.r.t. Ip: where this workgroup's pixels sampled the pattern
+        int bx[PPL], by[PPL];
+        bool on[PPL];
+#pragma unroll
+        for (int i = 0; i < PPL; ++i) {
+            const bool in = p0 + 64 * i < HW;
+            bx[i] = in ? t[i].x0 : 0;
+            by[i] = in ? t[i].y0 : 0;
+            on[i] = in && mv[i] != 0.0f && t[i].x0 != t[i].x1 && t[i].y0 != t[i].y1;
+        }
+        emit_tap_index(tap_index_at(tap_index, B, gridDim.x, b), bx, by, on);
     }
 }
 
@@ -254,34 +267,32 @@ __global__ __launch_bounds__(NT) void bilinear_bwd_grid_kernel(const float* __re
 }
 
 // ---------------------------------------------------------------------------------------
-// d out / d img for C == 1: scatter-add through per-wavefront LDS windows
+// d out / d img for C == 1.
 //
-// Scatter: each wavefront owns a 32x8 tile of target pixels (four neighbouring pixels of a row
-//   per lane).  It finds the bounding box of the
-//   source pixels its taps touch (DPP min/max) and sums all taps into a private LDS window of
-//   that box.  LDS float atomics retire about one lane every three cycles on this chip, so the
-//   window is updated with plain read-add-write; lanes of one instruction that hit the same cell
-//   are serialised by an election through a byte-sized owner array.
-// Then either (no workspace; the default of the Python wrappers)
-//   the window is added to the zero-filled gradient image with global float atomics: about one
-//   atomic per pixel instead of four, but last-bit differences from run to run,
-// or (workspace given; torch's deterministic mode)
-//   the window is stored compactly ("slab") with its box, and a merge pass lets each workgroup
-//   own a 64x16 tile of the source image and add, in ascending tile order, every slab whose box
-//   overlaps it -> fixed summation order, reproducible bits; tiles whose box did not fit a window
-//   (discontinuous warps) are added with global float atomics in an overflow pass.
+// Default (tap index given): gather form, no atomics, no zero fill, fixed summation order.
+//   Every wavefront owns a GX x GY tile of the SOURCE image and keeps its sums in a private LDS
+//   window (the tile plus a one-cell apron, so that the four taps of a sample whose base cell lies
+//   in [x0-1, x0+GX-1] x [y0-1, y0+GY-1] all fall inside).  It looks up in the tap index which
+//   segments of SEG target pixels can touch its tile, loads those segments (four per step, one
+//   sample per lane), and adds the taps of the samples whose base cell is in range; at the end it
+//   stores the tile (not the apron) with plain 16-byte stores.  A tap that falls into the apron of
+//   one tile is added again by the tile that owns the cell, so every cell is written exactly once,
+//   by one wavefront, with every contribution in it.  A segment near a tile border is loaded by two
+//   or four wavefronts: at 64 x 16 tiles about 1.5 loads per sample, served by L2.
+//   LDS float atomics retire about one lane every three cycles on this chip, so the window is
+//   updated with plain read-add-write; lanes of one instruction that hit the same cell are
+//   serialised by an election through a byte-sized owner array.
+// Without an index (workspace == NULL): scatter form.  Each wavefront owns a 32x8 tile of target
+//   pixels, sums their taps in an LDS window of the tile's bounding box and adds the window to the
+//   zero-filled gradient image with global float atomics (about one per pixel instead of four;
+//   last-bit differences from run to run).
 //
 // A sample whose two x corners (or two y corners) were clamped onto the same source pixel
 // contributes +w and -w to that pixel, i.e. exactly nothing; such samples are skipped.
 // ---------------------------------------------------------------------------------------
-// Wavefront tile: 8 lanes x 4 neighbouring pixels in each of 8 rows.  (64 x 4 loads a little faster
-// still -- 56.8 against 58 us at 32x512x512 -- but its box under a 20 degree rotation no longer fits
-// the window and the kernel falls from 39 to 85 us there.)
-constexpr int WT_X = 32, WT_Y = 8;
+constexpr int WT_X = 32, WT_Y = 8;       // scatter form: wavefront tile of target pixels
 constexpr int WT_LX = WT_X / 4;          // lanes along x
-constexpr int WIN_CAP = 1024;            // cells per window / floats per slab
-
-struct TileMeta { int xmin, ymin, ww, wh; };   // ww = 0: empty, ww = -1: overflow
+constexpr int WIN_CAP = 1024;            // cells per window
 
 struct PxTaps {
     Taps t;
@@ -330,8 +341,7 @@ __device__ __forceinline__ void load_tile_taps(const float* __restrict__ g_out, 
     bool vis[4];
     {
         // a lane owns four neighbouring pixels of one row: one 16-byte load of g, two of the grid, one
-        // 4-byte load of the mask (measured against one pixel per lane and load: 58 instead of 64 us
-        // for the whole kernel at 32x512x512)
+        // 4-byte load of the mask
         const int x = tx0 + 4 * (lane % WT_LX), y = ty0 + lane / WT_LX;
         const bool vec = (Wt % 4 == 0) && ((reinterpret_cast<uintptr_t>(g_out) | reinterpret_cast<uintptr_t>(grid)) % 16 == 0) &&
                          (!mask_u8 || reinterpret_cast<uintptr_t>(mask_u8) % 4 == 0);
@@ -377,7 +387,7 @@ __device__ __forceinline__ void load_tile_taps(const float* __restrict__ g_out, 
 // base cells c have distinct cells in each of the four add instructions: one election on c
 // covers all four.  The adds stay separate instructions in program order because lane i's c+1
 // may be lane j's c.
-__device__ __forceinline__ void window_add4(volatile float* win, volatile uint8_t* own, int c, int ww, float v00,
+__device__ __forceinline__ void window_add4(lds_vfloat win, lds_vu8 own, int c, int ww, float v00,
                                             float v10, float v01, float v11, bool active, int lane) {
     bool pend = active;
     do {
@@ -394,11 +404,9 @@ __device__ __forceinline__ void window_add4(volatile float* win, volatile uint8_
     } while (__builtin_expect(__ballot(pend) != 0, 0));
 }
 
-template <bool DIRECT>
 __global__ __launch_bounds__(NT) void bilinear_bwd_img_scatter_kernel(
     const float* __restrict__ g_out, const float* __restrict__ grid, const uint8_t* __restrict__ mask_u8, int Hs,
-    int Ws, int Ht, int Wt, int tiles_x, int ntiles, TileMeta* __restrict__ meta, float* __restrict__ slab,
-    float* __restrict__ g_img) {
+    int Ws, int Ht, int Wt, int tiles_x, int ntiles, float* __restrict__ g_img) {
     __shared__ __align__(16) float s_win[NT / 64][WIN_CAP];
     __shared__ uint8_t s_own[NT / 64][WIN_CAP];
     const int b = blockIdx.y;
@@ -421,8 +429,8 @@ __global__ __launch_bounds__(NT) void bilinear_bwd_img_scatter_kernel(
     const int ww = empty ? 0 : xmax - xmin + 1, wh = empty ? 0 : ymax - ymin + 1;
     const bool fits = (long)ww * wh <= WIN_CAP;
     const int n = fits ? ww * wh : 0;
-    volatile float* w = s_win[wv];
-    volatile uint8_t* own = s_own[wv];
+    lds_vfloat w = lds_ptr(s_win[wv]);
+    lds_vu8 own = lds_ptr(s_own[wv]);
     {   // clear the window, 16 bytes per lane and step (a few cells past n do no harm: n <= WIN_CAP)
         float4* w4 = reinterpret_cast<float4*>(s_win[wv]);
         for (int i = lane; 4 * i < n; i += 64) w4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -437,146 +445,271 @@ __global__ __launch_bounds__(NT) void bilinear_bwd_img_scatter_kernel(
                         (tp.wx0 * tp.wy1) * px[k].v, (tp.wx1 * tp.wy1) * px[k].v, on, lane);
         }
     }
-    if (DIRECT) {
-        float* o = g_img + (long)b * Hs * Ws;
-        if (n > 0) {
-            const unsigned o0 = (unsigned)(ymin * Ws + xmin);
-            const unsigned magic = ((1u << 20) + (unsigned)ww - 1u) / (unsigned)ww;   // i / ww == (i * magic) >> 20 while i * ww < 2^20
-            for (int i = lane; i < n; i += 64) {
-                const float v = w[i];
-                const unsigned r = ((unsigned)i * magic) >> 20;
-                const unsigned c = (unsigned)i - r * (unsigned)ww;
-                if (v != 0.0f)
-                    atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(o) + (o0 + r * (unsigned)Ws + c) * 4u), v);
-            }
-        } else if (!empty) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (px[k].on) {
-                    const Taps& tp = px[k].t;
-                    atomicAdd(o + (long)tp.y0 * Ws + tp.x0, (tp.wx0 * tp.wy0) * px[k].v);
-                    atomicAdd(o + (long)tp.y1 * Ws + tp.x0, (tp.wx0 * tp.wy1) * px[k].v);
-                    atomicAdd(o + (long)tp.y0 * Ws + tp.x1, (tp.wx1 * tp.wy0) * px[k].v);
-                    atomicAdd(o + (long)tp.y1 * Ws + tp.x1, (tp.wx1 * tp.wy1) * px[k].v);
-                }
+    float* o = g_img + (long)b * Hs * Ws;
+    if (n > 0) {
+        const unsigned o0 = (unsigned)(ymin * Ws + xmin);
+        const unsigned magic = ((1u << 20) + (unsigned)ww - 1u) / (unsigned)ww;   // i / ww == (i * magic) >> 20 while i * ww < 2^20
+        for (int i = lane; i < n; i += 64) {
+            const float v = w[i];
+            const unsigned r = ((unsigned)i * magic) >> 20;
+            const unsigned c = (unsigned)i - r * (unsigned)ww;
+            if (v != 0.0f)
+                atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(o) + (o0 + r * (unsigned)Ws + c) * 4u), v);
         }
-        return;
-    }
-    const long tg = (long)b * ntiles + t;
-    float* s = slab + tg * WIN_CAP;
-    for (int i = lane; i < n; i += 64) s[i] = w[i];
-    if (lane == 0) {
-        TileMeta m;
-        m.xmin = empty ? 0 : xmin; m.ymin = empty ? 0 : ymin;
-        m.ww = empty ? 0 : (fits ? ww : -1); m.wh = wh;
-        meta[tg] = m;
+    } else if (!empty) {   // the tile's taps spread over more cells than a window holds (a depth discontinuity)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (px[k].on) {
+                const Taps& tp = px[k].t;
+                atomicAdd(o + (long)tp.y0 * Ws + tp.x0, (tp.wx0 * tp.wy0) * px[k].v);
+                atomicAdd(o + (long)tp.y1 * Ws + tp.x0, (tp.wx0 * tp.wy1) * px[k].v);
+                atomicAdd(o + (long)tp.y0 * Ws + tp.x1, (tp.wx1 * tp.wy0) * px[k].v);
+                atomicAdd(o + (long)tp.y1 * Ws + tp.x1, (tp.wx1 * tp.wy1) * px[k].v);
+            }
     }
 }
 
-constexpr int MT_X = 64, MT_Y = 16;      // merge tile of the source image
-constexpr int LIST_CAP = 512;
-
-__global__ __launch_bounds__(NT) void bilinear_bwd_img_merge_kernel(const TileMeta* __restrict__ meta,
-                                                                    const float* __restrict__ slab, int ntiles,
-                                                                    int Hs, int Ws, float* __restrict__ g_img) {
-    __shared__ TileMeta s_list[LIST_CAP];
-    __shared__ int s_tile[LIST_CAP];
-    __shared__ int s_wcnt[NT / 64];
-    const int b = blockIdx.z;
-    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-    const int bx0 = blockIdx.x * MT_X, by0 = blockIdx.y * MT_Y;
-    const int x = bx0 + lane;                       // a wavefront reads 64 neighbouring pixels of a row
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};            // rows by0 + wv + 4*i
-    const TileMeta* mb = meta + (long)b * ntiles;
-    const float* sb = slab + (long)b * ntiles * WIN_CAP;
-    int count = 0;
-
-    auto flush = [&](int total) {
-        for (int j0 = 0; j0 < total; j0 += 4) {
-            float v[4][4];
+// The tap index of a grid on its own (the sampler's forward kernel inside warp_p2c writes the same
+// index while it samples): same pixel-to-lane mapping as the streaming kernels.
+__global__ __launch_bounds__(NT) void bilinear_tap_index_kernel(const float* __restrict__ grid,
+                                                               const uint8_t* __restrict__ mask_u8, int Hs, int Ws,
+                                                               long HWt, void* __restrict__ tap_index, int B) {
+    const int b = blockIdx.y;
+    const long p0 = lane_first_pixel();
+    const float2* gb = reinterpret_cast<const float2*>(grid) + (long)b * HWt;
+    const uint8_t* mb = mask_u8 ? mask_u8 + (long)b * HWt : nullptr;
+    float2 g[PPL];
+    uint8_t mk[PPL];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = j0 + u;
-                TileMeta e = {0, 0, 0, 0};
-                const float* base = sb;
-                if (j < total) {
-                    e = s_list[j];
-                    base = sb + (long)s_tile[j] * WIN_CAP;
-                }
-                const int cx = x - e.xmin;
-                const bool inx = (cx >= 0) && (cx < e.ww);
+    for (int i = 0; i < PPL; ++i) {
+        const long p = min(p0 + 64 * i, HWt - 1);
+        g[i] = gb[p];
+        mk[i] = mb ? mb[p] : (uint8_t)1;
+    }
+    int bx[PPL], by[PPL];
+    bool on[PPL];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int ry = by0 + wv + 4 * i - e.ymin;
-                    v[u][i] = (inx && ry >= 0 && ry < e.wh) ? base[ry * e.ww + cx] : 0.0f;
-                }
+    for (int i = 0; i < PPL; ++i) {
+        const Taps t = make_taps(g[i].x, g[i].y, Hs, Ws);
+        bx[i] = t.x0;
+        by[i] = t.y0;
+        on[i] = (p0 + 64 * i < HWt) && mk[i] != 0 && t.x0 != t.x1 && t.y0 != t.y1;
+    }
+    emit_tap_index(tap_index_at(tap_index, B, gridDim.x, b), bx, by, on);
+}
+
+#ifndef FC3D_GATHER_GY
+#define FC3D_GATHER_GY 16
+#endif
+constexpr int GX = 64, GY = FC3D_GATHER_GY;   // source tile of one wavefront
+constexpr int GWS = GX + 8;                   // window row stride: tile column 0 at window column 4 (16-byte aligned rows)
+constexpr int GWR = GY + 2;                   // window rows: tile row 0 at window row 1
+constexpr int G_GROUPS = NT * 2;              // group boxes the workgroup scans per round
+constexpr int G_UNROLL = 2;                   // run-level steps (64 boxes each) whose loads are in flight together
+constexpr int G_RUNS = 64 + 64 * G_UNROLL;    // run list: handed on above 64 entries, one round adds at most 64 * G_UNROLL
+constexpr int G_CAND = 128;                   // candidate segments: drained above 64, one step adds at most 64
+constexpr int G_DEPTH = 8;                    // sample steps whose loads are in flight together
+constexpr int G_OWN = 256;                    // election slots (cells hash onto them)
+
+struct GatherSample {
+    float2 g;
+    float v;
+    bool live;
+};
+
+// appends the lanes with `hit` to list[n..] in lane order; returns the new length
+template <typename L, typename V>
+__device__ __forceinline__ int list_append(L list, int n, bool hit, V value, int lane) {
+    const unsigned long long bal = __ballot(hit);
+    if (hit) list[n + __popcll(bal & ((1ull << lane) - 1ull))] = value;
+    return n + __popcll(bal);
+}
+
+// window_add4 with the election slots shared by all cells that agree in the low bits of their
+// index: two lanes with different cells may now meet in a slot, in which case one of them simply
+// waits a turn.
+__device__ __forceinline__ void window_add4_hashed(lds_vfloat win, lds_vu8 own, int c, int ww, float v00, float v10,
+                                                   float v01, float v11, bool active, int lane) {
+    bool pend = active;
+    const int slot = c & (G_OWN - 1);
+    do {
+        if (pend) {
+            own[slot] = (uint8_t)lane;
+            if (own[slot] == (uint8_t)lane) {
+                win[c] = win[c] + v00;
+                win[c + 1] = win[c + 1] + v10;
+                win[c + ww] = win[c + ww] + v01;
+                win[c + ww + 1] = win[c + ww + 1] + v11;
+                pend = false;
             }
+        }
+    } while (__builtin_expect(__ballot(pend) != 0, 0));
+}
+
+__global__ __launch_bounds__(NT) void bilinear_bwd_img_gather_kernel(
+    const float* __restrict__ g_out, const float* __restrict__ grid, void* __restrict__ tap_index, int B, int groups,
+    int Hs, int Ws, unsigned HWt, float* __restrict__ g_img) {
+    __shared__ __align__(16) float s_win[NT / 64][GWR * GWS];
+    __shared__ uint8_t s_own[NT / 64][G_OWN];
+    __shared__ int s_ghit[NT / 64][G_GROUPS / (NT / 64)];   // groups that meet the workgroup's row of tiles, per scanning wavefront
+    __shared__ int s_ng[NT / 64];
+    __shared__ int s_rhit[NT / 64][G_RUNS];
+    __shared__ int s_cand[NT / 64][2 * G_CAND];             // segment ids, then their live bits
+    const int b = blockIdx.z;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int rx0 = blockIdx.x * (NT / 64) * GX;            // the workgroup's NT/64 tiles lie side by side
+    const int sx0 = rx0 + wv * GX, sy0 = blockIdx.y * GY;
+    const bool tile_live = sx0 < Ws;
+    // base cells whose taps reach the workgroup's tiles / this wavefront's tile
+    const int rbx0 = rx0 - 1, rbx1 = rx0 + (NT / 64) * GX - 1, by0 = sy0 - 1, by1 = sy0 + GY - 1;
+    const int bx0 = sx0 - 1, bx1 = sx0 + GX - 1;
+    const float fbx0 = (float)bx0, fbx1 = (float)bx1, fby0 = (float)by0, fby1 = (float)by1;
+    const TapIndex ix = tap_index_at(tap_index, B, groups, b);
+    const float2* gb = reinterpret_cast<const float2*>(grid) + (long)b * HWt;
+    const float* vb = g_out + (long)b * HWt;
+    lds_vfloat win = lds_ptr(s_win[wv]);
+    lds_vu8 own = lds_ptr(s_own[wv]);
+    lds_vint rhit = lds_ptr(s_rhit[wv]);
+    lds_vint cand = lds_ptr(s_cand[wv]), cbits = cand + G_CAND;
+    {
+        float4* w4 = reinterpret_cast<float4*>(s_win[wv]);
+        for (int i = lane; i < GWR * GWS / 4; i += 64) w4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+
+    auto fetch = [&](int e, int n) -> GatherSample {     // entry e of the candidate list, this lane's pixel of it
+        GatherSample sm;
+        const int j = min(e + (lane >> 4), n - 1);
+        const int seg = cand[j], bits = cbits[j];
+        const unsigned p = (unsigned)seg * SEG + (lane & 15);
+        sm.live = (e + (lane >> 4) < n) && ((bits >> (lane & 15)) & 1);      // a live pixel lies inside the target image
+        const unsigned q = min(p, HWt - 1u);
+        sm.g = ld_at(gb, q);
+        sm.v = ld_at(vb, q);
+        return sm;
+    };
+    // A live sample's corners were not clamped: x0 = floor x, x1 = x0 + 1, and the weights are those
+    // of make_taps (x1 - x, x - x0; the corners are exact in fp32).
+    auto add = [&](const GatherSample& sm) {
+        const float fx = floorf(sm.g.x), fy = floorf(sm.g.y);
+        const bool on = sm.live && fx >= fbx0 && fx <= fbx1 && fy >= fby0 && fy <= fby1;
+        const float wx1 = __fsub_rn(sm.g.x, fx), wx0 = __fsub_rn(__fadd_rn(fx, 1.0f), sm.g.x);
+        const float wy1 = __fsub_rn(sm.g.y, fy), wy0 = __fsub_rn(__fadd_rn(fy, 1.0f), sm.g.y);
+        const int c = on ? (int)(__fsub_rn(fy, fby0) * (float)GWS + __fsub_rn(fx, (float)(sx0 - 4))) : 0;
+        window_add4_hashed(win, own, c, GWS, (wx0 * wy0) * sm.v, (wx1 * wy0) * sm.v, (wx0 * wy1) * sm.v,
+                           (wx1 * wy1) * sm.v, on, lane);
+    };
+    // the first n candidate segments, 64 / SEG per step; the loads of G_DEPTH steps are issued
+    // together so that one memory latency covers them all
+    auto drain = [&](int n) {
+        constexpr int STEP = 64 / SEG;
+        for (int e0 = 0; e0 < n; e0 += STEP * G_DEPTH) {
+            GatherSample sm[G_DEPTH];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int d = 0; d < G_DEPTH; ++d)
+                if (e0 + d * STEP < n) sm[d] = fetch(e0 + d * STEP, n);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i] += v[u][i];   // ascending tile order, u after u
+            for (int d = 0; d < G_DEPTH; ++d)
+                if (e0 + d * STEP < n) add(sm[d]);
         }
     };
 
-    for (int base = 0; base < ntiles; base += NT) {
-        const int t = base + tid;
-        TileMeta m = {0, 0, 0, 0};
-        bool hit = false;
-        if (t < ntiles) {
-            m = mb[t];
-            hit = (m.ww > 0) && (m.xmin < bx0 + MT_X) && (m.xmin + m.ww > bx0) && (m.ymin < by0 + MT_Y) &&
-                  (m.ymin + m.wh > by0);
-        }
-        const unsigned long long bal = __ballot(hit);
-        if (lane == 0) s_wcnt[wv] = __popcll(bal);
-        __syncthreads();
-        int off = count, total = count;
+    // Three nested scans, each filling a list that the next level consumes: groups (scanned by the
+    // whole workgroup against its row of tiles) -> runs -> segments -> samples (per wavefront, against
+    // its own tile).  A list is handed on when it holds more than 64 entries or when its producer is
+    // done; every loop runs one extra pass that only flushes, so that each level's code exists once.
+    constexpr int GPS = 64 / RUN_PER_GROUP, RPS = 64 / SEG_PER_RUN;   // group hits / run hits whose children fill one step
+    constexpr int GPW = G_GROUPS / NT;                                // group steps per wavefront and round
+    int nr = 0, ncand = 0;
+    for (int c0 = 0; c0 < groups; c0 += G_GROUPS) {
+        const bool fin_g = c0 + G_GROUPS >= groups;
+        int2 gbox[GPW];
 #pragma unroll
-        for (int i = 0; i < NT / 64; ++i) {
-            if (i < wv) off += s_wcnt[i];
-            total += s_wcnt[i];
-        }
-        if (hit) {
-            const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));
-            s_list[pos] = m;
-            s_tile[pos] = t;
-        }
-        __syncthreads();
-        count = total;
-        if (count > LIST_CAP - NT || base + NT >= ntiles) {
-            flush(count);
-            count = 0;
-            __syncthreads();
-        }
-    }
+        for (int u = 0; u < GPW; ++u) gbox[u] = ix.group[min(c0 + (wv * GPW + u) * 64 + lane, groups - 1)];
+        int cnt = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int y = by0 + wv + 4 * i;
-        if (y < Hs && x < Ws) g_img[(long)b * Hs * Ws + (long)y * Ws + x] = acc[i];
+        for (int u = 0; u < GPW; ++u) {
+            const int g = c0 + (wv * GPW + u) * 64 + lane;
+            cnt = list_append(lds_ptr(s_ghit[wv]), cnt, g < groups && box_meets(gbox[u], rbx0, rbx1, by0, by1), g, lane);
+        }
+        if (lane == 0) s_ng[wv] = cnt;
+        __syncthreads();
+        if (tile_live) {
+            int off[NT / 64 + 1];
+            off[0] = 0;
+#pragma unroll
+            for (int w2 = 0; w2 < NT / 64; ++w2) off[w2 + 1] = off[w2] + s_ng[w2];
+            const int ng = off[NT / 64];
+            const int rounds_r = (ng + GPS * G_UNROLL - 1) / (GPS * G_UNROLL);
+            for (int rr = 0; rr <= rounds_r; ++rr) {
+                const bool fin_r = rr == rounds_r;
+                if (!fin_r) {
+                    int run[G_UNROLL];
+                    int2 rb[G_UNROLL];
+#pragma unroll
+                    for (int u = 0; u < G_UNROLL; ++u) {
+                        const int j = min((rr * G_UNROLL + u) * GPS + lane / RUN_PER_GROUP, ng - 1);
+                        int w2 = 0;
+#pragma unroll
+                        for (int q = 1; q < NT / 64; ++q) w2 += (j >= off[q]) ? 1 : 0;
+                        int base = 0;
+#pragma unroll
+                        for (int q = 1; q < NT / 64; ++q) base = (w2 == q) ? off[q] : base;
+                        run[u] = lds_ptr(s_ghit[0])[w2 * (G_GROUPS / (NT / 64)) + j - base] * RUN_PER_GROUP + lane % RUN_PER_GROUP;
+                        rb[u] = ix.run[run[u]];
+                    }
+#pragma unroll
+                    for (int u = 0; u < G_UNROLL; ++u) {
+                        const int j = (rr * G_UNROLL + u) * GPS + lane / RUN_PER_GROUP;
+                        nr = list_append(rhit, nr, j < ng && box_meets(rb[u], bx0, bx1, by0, by1), run[u], lane);
+                    }
+                }
+                if (nr <= 64 && !fin_r) continue;
+                const int rounds_s = (nr + RPS - 1) / RPS;
+                for (int rs = 0; rs <= rounds_s; ++rs) {
+                    const bool fin_s = rs == rounds_s;
+                    if (!fin_s) {
+                        const int j = rs * RPS + lane / SEG_PER_RUN;
+                        const int seg = rhit[min(j, nr - 1)] * SEG_PER_RUN + lane % SEG_PER_RUN;
+                        const int2 sb = ix.seg[seg];
+                        const bool hit = j < nr && seg_meets(sb, bx0, bx1, by0, by1);
+                        list_append(cbits, ncand, hit, (int)((unsigned)sb.y >> 16), lane);
+                        ncand = list_append(cand, ncand, hit, seg, lane);
+                    }
+                    const bool last = fin_g && fin_r && fin_s;
+                    if (ncand <= 64 && !last) continue;
+                    const int m = last ? ncand : 64;
+                    if (m > 0) drain(m);
+                    const int rest = ncand - m;                  // < 64
+                    int keep_s = 0, keep_b = 0;
+                    if (lane < rest) { keep_s = cand[m + lane]; keep_b = cbits[m + lane]; }
+                    if (lane < rest) { cand[lane] = keep_s; cbits[lane] = keep_b; }
+                    ncand = rest;
+                }
+                nr = 0;
+            }
+        }
+        __syncthreads();                              // s_ghit is rewritten by the next round
     }
-}
+    if (!tile_live) return;
 
-__global__ __launch_bounds__(NT) void bilinear_bwd_img_overflow_kernel(
-    const float* __restrict__ g_out, const float* __restrict__ grid, const uint8_t* __restrict__ mask_u8, int Hs,
-    int Ws, int Ht, int Wt, int tiles_x, int ntiles, const TileMeta* __restrict__ meta, float* __restrict__ g_img) {
-    const int b = blockIdx.y;
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int t = blockIdx.x * (NT / 64) + wv;
-    if (t >= ntiles) return;
-    if (meta[(long)b * ntiles + t].ww != -1) return;
-    PxTaps px[4];
-    load_tile_taps(g_out, grid, mask_u8, (long)b * Ht * Wt, Ht, Wt, Hs, Ws, (t % tiles_x) * WT_X,
-                   (t / tiles_x) * WT_Y, lane, px);
+    // the tile goes out with plain stores: four rows of sixteen 16-byte groups per step
     float* o = g_img + (long)b * Hs * Ws;
+    const bool vec = (Ws % 4 == 0) && (reinterpret_cast<uintptr_t>(g_img) % 16 == 0);
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (px[k].on) {
-            const Taps& tp = px[k].t;
-            atomicAdd(o + (long)tp.y0 * Ws + tp.x0, (tp.wx0 * tp.wy0) * px[k].v);
-            atomicAdd(o + (long)tp.y1 * Ws + tp.x0, (tp.wx0 * tp.wy1) * px[k].v);
-            atomicAdd(o + (long)tp.y0 * Ws + tp.x1, (tp.wx1 * tp.wy0) * px[k].v);
-            atomicAdd(o + (long)tp.y1 * Ws + tp.x1, (tp.wx1 * tp.wy1) * px[k].v);
+    for (int r0 = 0; r0 < GY; r0 += 4) {
+        const int r = r0 + (lane >> 4), x = sx0 + 4 * (lane & 15), y = sy0 + r;
+        if (r < GY && y < Hs && x < Ws) {
+            const float4 v = *reinterpret_cast<const float4*>(&s_win[wv][(r + 1) * GWS + 4 + 4 * (lane & 15)]);
+            if (vec) {
+                st_at(reinterpret_cast<float4*>(o), ((unsigned)y * (unsigned)Ws + (unsigned)x) >> 2, v);
+            } else {
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (x + k < Ws) o[(long)y * Ws + x + k] = vv[k];
+            }
         }
+    }
 }
 
 // Any channel count: plain float atomics into a zeroed gradient image (the xyz sampling of
@@ -1062,19 +1195,41 @@ static inline int wave_tiles(int Ht, int Wt, int* tiles_x) {
     return *tiles_x * cdiv(Ht, WT_Y);
 }
 
+// the gather form needs 32-bit per-image byte offsets and 16-bit box fields
+static inline bool gather_fits(int Hs, int Ws, int Ht, int Wt) {
+    return Hs <= kTapIndexMaxDim && Ws <= kTapIndexMaxDim && (long)Ht * Wt < (1L << 29) && (long)Hs * Ws < (1L << 30);
+}
+
 extern "C" size_t fc3d_bilinear_bwd_img_workspace(int B, int Hs, int Ws, int C, int Ht, int Wt) {
-    if (B <= 0 || Hs <= 0 || Ws <= 0 || Ht <= 0 || Wt <= 0 || C != 1) return 0;
-    int tx;
-    const size_t nt = (size_t)B * wave_tiles(Ht, Wt, &tx);
-    return nt * sizeof(TileMeta) + nt * WIN_CAP * sizeof(float);
+    if (B <= 0 || Hs <= 0 || Ws <= 0 || Ht <= 0 || Wt <= 0 || C != 1 || !gather_fits(Hs, Ws, Ht, Wt)) return 0;
+    return (size_t)B * tap_index_groups(Ht, Wt) * (1 + RUN_PER_GROUP * (1 + SEG_PER_RUN)) * sizeof(int2);
+}
+
+static int launch_tap_index(hipStream_t s, const float* grid, const uint8_t* mask_u8, int B, int Hs, int Ws, int Ht,
+                            int Wt, void* index) {
+    FC3D_LAUNCH("bilinear_tap_index", bilinear_tap_index_kernel, dim3((unsigned)tap_index_groups(Ht, Wt), B), dim3(NT), 0, s,
+                grid, mask_u8, Hs, Ws, (long)Ht * Wt, index, B);
+    return FC3D_OK;
+}
+
+extern "C" int fc3d_bilinear_tap_index(void* stream, const float* grid, const uint8_t* mask_u8, int B, int Hs, int Ws,
+                                       int Ht, int Wt, void* index) {
+    if (!grid || !index) return FC3D_EINVAL;
+    if (int e = check_img(B, Hs, Ws)) return e;
+    if (int e = check_img(B, Ht, Wt)) return e;
+    if (!gather_fits(Hs, Ws, Ht, Wt)) return FC3D_ERANGE;
+    if ((reinterpret_cast<uintptr_t>(grid) & 7u) || (reinterpret_cast<uintptr_t>(index) & 7u)) return FC3D_EALIGN;
+    return launch_tap_index((hipStream_t)stream, grid, mask_u8, B, Hs, Ws, Ht, Wt, index);
 }
 
 extern "C" int fc3d_bilinear_bwd_img(void* stream, const float* g_out, const float* grid, const uint8_t* mask_u8,
-                                     int B, int Hs, int Ws, int C, int Ht, int Wt, void* workspace, float* g_img) {
+                                     int B, int Hs, int Ws, int C, int Ht, int Wt, void* index, int index_ready,
+                                     float* g_img) {
     if (!g_out || !grid || !g_img || C <= 0) return FC3D_EINVAL;
     if (int e = check_img(B, Hs, Ws)) return e;
     if (int e = check_img(B, Ht, Wt)) return e;
     if ((long)B * Hs * Ws * C >= (1L << 31) || (long)B * Ht * Wt * C >= (1L << 31)) return FC3D_ERANGE;
+    if ((long)Ht * Wt >= (1L << 29) || (long)Hs * Ws >= (1L << 30)) return FC3D_ERANGE;   // per-image byte offsets are 32-bit
     if (reinterpret_cast<uintptr_t>(grid) & 7u) return FC3D_EALIGN;
     hipStream_t s = (hipStream_t)stream;
     if (C != 1) {
@@ -1082,30 +1237,24 @@ extern "C" int fc3d_bilinear_bwd_img(void* stream, const float* g_out, const flo
         const long np = (long)Ht * Wt;
         FC3D_LAUNCH("bilinear_bwd_img_atomic", bilinear_bwd_img_atomic_kernel, dim3(cdiv(np, NT), B), dim3(NT), 0, s, g_out, grid, mask_u8,
                            Hs, Ws, C, np, g_img);
-        FC3D_LAUNCH_CHECK();
         return FC3D_OK;
     }
-    int tiles_x;
-    const int ntiles = wave_tiles(Ht, Wt, &tiles_x);
-    const dim3 gs(cdiv(ntiles, NT / 64), B), blk(NT);
-    if (!workspace) {   // window sums go straight into the zeroed gradient image with float atomics
+    if (!index) {   // window sums go straight into the zeroed gradient image with float atomics
+        int tiles_x;
+        const int ntiles = wave_tiles(Ht, Wt, &tiles_x);
         if (int e = zero_fill(s, g_img, (size_t)B * Hs * Ws * sizeof(float))) return e;
-        FC3D_LAUNCH("bilinear_bwd_img_scatter", bilinear_bwd_img_scatter_kernel<true>, gs, blk, 0, s, g_out, grid, mask_u8, Hs, Ws, Ht, Wt, tiles_x,
-                       ntiles, (TileMeta*)nullptr, (float*)nullptr, g_img);
+        FC3D_LAUNCH("bilinear_bwd_img_scatter", bilinear_bwd_img_scatter_kernel, dim3(cdiv(ntiles, NT / 64), B), dim3(NT), 0, s,
+                    g_out, grid, mask_u8, Hs, Ws, Ht, Wt, tiles_x, ntiles, g_img);
         return FC3D_OK;
     }
-    if (!aligned16(workspace)) return FC3D_EALIGN;
-    TileMeta* meta = (TileMeta*)workspace;
-    float* slab = (float*)(meta + (size_t)B * ntiles);
-    FC3D_LAUNCH("bilinear_bwd_img_scatter", bilinear_bwd_img_scatter_kernel<false>, gs, blk, 0, s, g_out, grid, mask_u8, Hs, Ws, Ht, Wt, tiles_x,
-                       ntiles, meta, slab, g_img);
-    FC3D_LAUNCH_CHECK();
-    FC3D_LAUNCH("bilinear_bwd_img_merge", bilinear_bwd_img_merge_kernel, dim3(cdiv(Ws, MT_X), cdiv(Hs, MT_Y), B), blk, 0, s,
-                       (const TileMeta*)meta, (const float*)slab, ntiles, Hs, Ws, g_img);
-    FC3D_LAUNCH_CHECK();
-    FC3D_LAUNCH("bilinear_bwd_img_overflow", bilinear_bwd_img_overflow_kernel, gs, blk, 0, s, g_out, grid, mask_u8, Hs, Ws, Ht, Wt, tiles_x,
-                       ntiles, (const TileMeta*)meta, g_img);
-    FC3D_LAUNCH_CHECK();
+    if (!gather_fits(Hs, Ws, Ht, Wt)) return FC3D_ERANGE;
+    if (reinterpret_cast<uintptr_t>(index) & 7u) return FC3D_EALIGN;
+    if (!index_ready) {
+        if (int e = launch_tap_index(s, grid, mask_u8, B, Hs, Ws, Ht, Wt, index)) return e;
+    }
+    FC3D_LAUNCH("bilinear_bwd_img_gather", bilinear_bwd_img_gather_kernel, dim3(cdiv(Ws, (NT / 64) * GX), cdiv(Hs, GY), B),
+                dim3(NT), 0, s, g_out, grid, index, B, (int)tap_index_groups(Ht, Wt), Hs, Ws,
+                (unsigned)((long)Ht * Wt), g_img);
     return FC3D_OK;
 }
 
@@ -1133,10 +1282,11 @@ extern "C" int fc3d_warp_p2c_fwd(void* stream, const float* Ip, const float* coo
                                  int64_t p_sh, int64_t p_sw, const float* coord_c, int64_t c_sb, int64_t c_sc,
                                  int64_t c_sh, int64_t c_sw, const float* T_p2c, const float* T_c2p, int B, int H,
                                  int W, float* Ic_masked, float* grid_p2c, float* grid_c2p, uint8_t* mask_u8,
-                                 int mask_is_clear) {
+                                 int mask_is_clear, void* tap_index) {
     if (!Ip || !coord_p || !coord_c || !T_p2c || !T_c2p || !Ic_masked || !grid_p2c || !grid_c2p || !mask_u8)
         return FC3D_EINVAL;
     if (int e = check_img(B, H, W)) return e;
+    if (tap_index && (!gather_fits(H, W, H, W) || (reinterpret_cast<uintptr_t>(tap_index) & 7u))) return FC3D_ERANGE;
     if (!aligned4(coord_p) || !aligned4(coord_c) || !aligned4(Ip) || !aligned4(Ic_masked) ||
         (reinterpret_cast<uintptr_t>(grid_p2c) & 7u) || (reinterpret_cast<uintptr_t>(grid_c2p) & 7u))
         return FC3D_EALIGN;
@@ -1155,7 +1305,7 @@ extern "C" int fc3d_warp_p2c_fwd(void* stream, const float* Ip, const float* coo
     }
     {
         const int layout = pick_layout(coord_c, c_sc, c_sh, c_sw, W);
-#define ARGS coord_c, (long)c_sb, (long)c_sc, (long)c_sh, (long)c_sw, T_c2p, Ip, (const uint8_t*)mask_u8, H, W, grid_c2p, Ic_masked
+#define ARGS coord_c, (long)c_sb, (long)c_sc, (long)c_sh, (long)c_sw, T_c2p, Ip, (const uint8_t*)mask_u8, H, W, grid_c2p, Ic_masked, tap_index, B
         FC3D_DISPATCH_LAYOUT("warp_sample", warp_sample_kernel, layout, fma);
 #undef ARGS
         FC3D_LAUNCH_CHECK();

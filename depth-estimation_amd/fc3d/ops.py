@@ -220,19 +220,43 @@ class ProjectFn(torch.autograd.Function):
         return gc, None
 
 
-def _bilinear_bwd_img(g, grid, mask, B, Hs, Ws, C, Ht, Wt):
+_IMG_GRAD_MODE = "ordered"
+
+
+def set_image_gradient_mode(mode: str) -> str:
+    """How d out / d img of the bilinear sampler (and of warp_p2c) is accumulated for one-channel
+    images: "ordered" (default): gather form, no atomics, fixed summation order; "atomic": scatter
+    form with global float atomics.  torch.use_deterministic_algorithms(True) always selects
+    "ordered".  Returns the previous mode."""
+    global _IMG_GRAD_MODE
+    if mode not in ("ordered", "atomic"):
+        raise ValueError(f"unknown image-gradient mode {mode!r}")
+    old, _IMG_GRAD_MODE = _IMG_GRAD_MODE, mode
+    return old
+
+
+def _img_grad_ordered() -> bool:
+    return _IMG_GRAD_MODE == "ordered" or torch.are_deterministic_algorithms_enabled()
+
+
+def _tap_index_buffer(B, Hs, Ws, Ht, Wt, dev):
+    """Storage for the tap index of a [B,Ht,Wt,2] grid into a one-channel [B,Hs,Ws] image, or None
+    where the gather form does not apply."""
+    nbytes = _lib.fc3d_bilinear_bwd_img_workspace(B, Hs, Ws, 1, Ht, Wt)
+    return torch.empty(nbytes // 8, dtype=torch.int64, device=dev) if nbytes else None
+
+
+def _bilinear_bwd_img(g, grid, mask, B, Hs, Ws, C, Ht, Wt, index=None):
     dev = g.device
-    # torch.use_deterministic_algorithms(True) selects the fixed-order merge (needs a workspace);
-    # otherwise the per-wavefront sums are accumulated with float atomics, which is faster
-    ws = None
-    if C == 1 and torch.are_deterministic_algorithms_enabled():
-        nbytes = _lib.fc3d_bilinear_bwd_img_workspace(B, Hs, Ws, C, Ht, Wt)
-        ws = torch.empty(max(16, nbytes) // 4, dtype=torch.float32, device=dev)
+    ready = index is not None
+    if not ready and C == 1 and _img_grad_ordered():
+        index = _tap_index_buffer(B, Hs, Ws, Ht, Wt, dev)
     gi = torch.empty((B, Hs, Ws, C), dtype=torch.float32, device=dev)
     with _on_device(dev):
         _check(_lib.fc3d_bilinear_bwd_img(_stream(), g.data_ptr(), grid.data_ptr(),
                                           mask.data_ptr() if mask is not None else None, B, Hs, Ws, C, Ht, Wt,
-                                          ws.data_ptr() if ws is not None else None, gi.data_ptr()),
+                                          index.data_ptr() if index is not None else None, int(ready),
+                                          gi.data_ptr()),
                "fc3d_bilinear_bwd_img")
     return gi
 
@@ -309,12 +333,15 @@ class WarpP2CFn(torch.autograd.Function):
                           not zero_mask.is_contiguous() or zero_mask.device != dev):
             raise RuntimeError("warp_p2c: zero_mask must be a dense uint8 [B,H,W] tensor on the inputs' device")
         mask = zero_mask if have_zero else torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+        # the sampling kernel also notes where its pixels landed, for the gradient w.r.t. Ip
+        index = _tap_index_buffer(B, H, W, H, W, dev) if (ctx.needs_input_grad[0] and _img_grad_ordered()) else None
         with _on_device(dev):
             _check(_lib.fc3d_warp_p2c_fwd(_stream(), ip.data_ptr(), coord_p.data_ptr(), sp[0], sp[1], sp[2], sp[3],
                                           coord_c.data_ptr(), sc[0], sc[1], sc[2], sc[3], T_p2c.data_ptr(),
                                           T_c2p.data_ptr(), B, H, W, Ic.data_ptr(), gp2c.data_ptr(), gc2p.data_ptr(),
-                                          mask.data_ptr(), int(have_zero)), "fc3d_warp_p2c_fwd")
-        ctx.save_for_backward(gc2p, mask)
+                                          mask.data_ptr(), int(have_zero),
+                                          index.data_ptr() if index is not None else None), "fc3d_warp_p2c_fwd")
+        ctx.save_for_backward(gc2p, mask, index)
         ctx.mark_non_differentiable(gp2c, gc2p, mask)
         ctx.set_materialize_grads(False)      # no zero tensors for the two grids and the mask
         return Ic, gp2c, gc2p, mask
@@ -323,9 +350,9 @@ class WarpP2CFn(torch.autograd.Function):
     def backward(ctx, g_Ic, _g1, _g2, _g3):
         if g_Ic is None:
             return None, None, None, None, None, None
-        gc2p, mask = ctx.saved_tensors
+        gc2p, mask, index = ctx.saved_tensors
         B, H, W, _ = gc2p.shape
-        gi = _bilinear_bwd_img(_dense(g_Ic), gc2p, mask, B, H, W, 1, H, W)
+        gi = _bilinear_bwd_img(_dense(g_Ic), gc2p, mask, B, H, W, 1, H, W, index=index)
         return gi, None, None, None, None, None
 
 

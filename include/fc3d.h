@@ -36,7 +36,7 @@ extern "C" {
 #define FC3D_EALIGN (-3)     /* pointer not aligned to its element type */
 #define FC3D_ESCRATCH (-4)   /* problem larger than the library's static scratch buffer */
 
-#define FC3D_VERSION 100
+#define FC3D_VERSION 200
 
 int fc3d_version(void);
 const char *fc3d_status_string(int status);
@@ -146,17 +146,28 @@ int fc3d_bilinear_bwd_grid(void *stream, const float *g_out, const float *img, c
                            const uint8_t *mask_u8, int B, int Hs, int Ws, int C, int Ht, int Wt,
                            float *g_grid);
 
-/* d out / d img (scatter-add of the four weighted taps), written -- not
- * accumulated -- to g_img [B][Hs][Ws][C].  For C == 1 every wavefront first sums
- * its samples in a private LDS window.  workspace == NULL: the windows are added
- * to g_img with float atomics (fastest; last-bit differences from run to run,
- * like the reference's index_put/scatter backward on a GPU).  workspace of
- * fc3d_bilinear_bwd_img_workspace() bytes: the windows are stored and merged in
- * a fixed order, bit-reproducible and free of global atomics.  C != 1 ignores
- * the workspace and uses atomics.                                             */
+/* d out / d img (the backward of the index gathers at geometry_pytorch.py:166-169: a scatter-add of
+ * the four weighted taps), written -- not accumulated -- to g_img [B][Hs][Ws][C].
+ * C == 1 with `index` (fc3d_bilinear_bwd_img_workspace() bytes, 8-byte aligned): gather form.  Every
+ * wavefront owns a 64x16 tile of the SOURCE image, finds through the tap index the target pixels
+ * that can touch it, sums their taps in LDS and stores the tile once: no atomics, no zero fill, a
+ * fixed summation order (bit-reproducible).  The tap index (two levels of boxes that say where runs
+ * of target pixels landed) is built by the call itself when index_ready == 0; fc3d_warp_p2c_fwd can
+ * write it while it samples (then pass index_ready != 0), and fc3d_bilinear_tap_index builds it on
+ * its own.  The index depends on grid, mask and the sizes only.  Built for locally smooth warps: a
+ * grid that sends neighbouring pixels all over the image stays correct but makes every tile visit
+ * every pixel.
+ * C == 1 with index == NULL: scatter form -- per-wavefront LDS windows added to the zero-filled
+ * g_img with float atomics (last-bit differences from run to run, like the reference's
+ * index_put/scatter backward on a GPU).  C != 1 always uses atomics.
+ * fc3d_bilinear_bwd_img_workspace returns 0 when the gather form does not apply (C != 1, a source
+ * side beyond 32767 pixels).                                                                  */
 size_t fc3d_bilinear_bwd_img_workspace(int B, int Hs, int Ws, int C, int Ht, int Wt);
+int fc3d_bilinear_tap_index(void *stream, const float *grid, const uint8_t *mask_u8, int B, int Hs, int Ws,
+                            int Ht, int Wt, void *index);
 int fc3d_bilinear_bwd_img(void *stream, const float *g_out, const float *grid, const uint8_t *mask_u8,
-                          int B, int Hs, int Ws, int C, int Ht, int Wt, void *workspace, float *g_img);
+                          int B, int Hs, int Ws, int C, int Ht, int Wt, void *index, int index_ready,
+                          float *g_img);
 
 /* gen_visible_mask, geometry_pytorch.py:180-222.  method 0 = 'all', 1 = 'round'.
  * Either output may be NULL; both are cleared by the call.                    */
@@ -166,13 +177,15 @@ int fc3d_visible_mask(void *stream, const float *grid, int B, int H, int W, int 
 /* warp_p2c forward, geometry_pytorch.py:255-281, given T_p2c = K*pose and
  * T_c2p = K*inverse(pose): writes grid_p2c, grid_c2p, the visibility mask and
  * Ic_masked = sample(Ip, grid_c2p) * mask.  mask_is_clear != 0: mask_u8 already
- * holds zeros (see fc3d_pose_transforms), skip clearing it.                   */
+ * holds zeros (see fc3d_pose_transforms), skip clearing it.  tap_index (may be
+ * NULL): fc3d_bilinear_bwd_img_workspace(B,H,W,1,H,W) bytes that receive the tap
+ * index of grid_c2p under the mask, for the backward pass w.r.t. Ip.          */
 int fc3d_warp_p2c_fwd(void *stream, const float *Ip,
                       const float *coord_p, int64_t p_sb, int64_t p_sc, int64_t p_sh, int64_t p_sw,
                       const float *coord_c, int64_t c_sb, int64_t c_sc, int64_t c_sh, int64_t c_sw,
                       const float *T_p2c, const float *T_c2p, int B, int H, int W,
                       float *Ic_masked, float *grid_p2c, float *grid_c2p, uint8_t *mask_u8,
-                      int mask_is_clear);
+                      int mask_is_clear, void *tap_index);
 
 /* points_in_camera_coords, geometry_pytorch.py:44-65: out [B][H][W][4] =
  * (z*rx, z*ry, z*rz, 1).  Rays either separable (ray_x[W], ray_y[H], rz = 1:

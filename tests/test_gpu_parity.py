@@ -268,21 +268,28 @@ def test_points_and_z2pointcloud(mods, golden):
     assert np.array_equal(G.get_intrinsic(2).cpu().numpy(), g0["intrinsic"])
 
 
-@pytest.mark.parametrize("deterministic", [False, True])
-def test_bilinear_golden(mods, golden, deterministic):
-    """Both image-gradient paths: float-atomic accumulation (default) and the fixed-order merge
-    that torch.use_deterministic_algorithms(True) selects."""
+@pytest.mark.parametrize("mode", ["ordered", "atomic", "atomic+deterministic"])
+def test_bilinear_golden(mods, golden, mode):
+    """Both image-gradient paths: the gather form without atomics (default) and float-atomic
+    accumulation; torch.use_deterministic_algorithms(True) selects the former whatever the mode."""
     g = golden("g4_bilinear")
     G = mods["G"]
     for tag in "abc":
         img = dev(g[f"{tag}_img"]).requires_grad_(True)
         co = dev(g[f"{tag}_coords"]).requires_grad_(True)
         out = G.bilinear_sampler(img, co)
-        torch.use_deterministic_algorithms(deterministic, warn_only=True)
+        old = mods["ops"].set_image_gradient_mode(mode.split("+")[0])
+        torch.use_deterministic_algorithms(mode.endswith("deterministic"), warn_only=True)
         try:
             out.backward(dev(g[f"{tag}_g"]))
+            grads = [img.grad.clone()]
+            if mode != "atomic" and img.shape[-1] == 1:   # one channel, fixed summation order: the same bits every time
+                img.grad = None
+                G.bilinear_sampler(img, co.detach()).backward(dev(g[f"{tag}_g"]))
+                assert torch.equal(grads[0], img.grad), tag
         finally:
             torch.use_deterministic_algorithms(False)
+            mods["ops"].set_image_gradient_mode(old)
         same = np.array_equal(out.detach().cpu().numpy(), g[f"{tag}_out"])
         assert same, tag
         # A sample a million pixels outside the image adds +-1e12-sized taps that cancel on one
@@ -301,6 +308,75 @@ def test_bilinear_golden(mods, golden, deterministic):
         assert e_img < TOL and e_co < TOL, (tag, e_img, e_co)
     img = torch.arange(16.0, device="cuda").reshape(1, 4, 4, 1) + 1
     assert float(G.bilinear_sampler(img, torch.tensor([[[[3.0, 3.0]]]], device="cuda"))) == 0.0
+
+
+@pytest.mark.parametrize("B,Hs,Ws,Ht,Wt,kind", [
+    (2, 37, 53, 37, 53, "smooth"), (1, 20, 70, 33, 41, "random"), (1, 130, 300, 64, 64, "zoom"),
+    (3, 5, 3, 5, 3, "smooth"), (1, 1, 1, 1, 1, "smooth"), (2, 64, 200, 64, 200, "jump"), (1, 96, 520, 40, 1030, "smooth")])
+def test_image_gradient_gather_form(mods, B, Hs, Ws, Ht, Wt, kind):
+    """d out / d img of the one-channel sampler in gather form (source tiles look up their samples
+    in the tap index) against a float64 scatter_add of the four weighted taps: ragged sizes,
+    source and target of different sizes, masks, coordinates outside the image, NaNs, grids that
+    are not smooth at all, and the index written by a separate call."""
+    ops = mods["ops"]
+    rs = np.random.RandomState(B * 1000 + Hs + Wt)
+    ys, xs = np.meshgrid(np.arange(Ht), np.arange(Wt), indexing="ij")
+    if kind == "random":
+        gx, gy = rs.uniform(-3, Ws + 3, (B, Ht, Wt)), rs.uniform(-3, Hs + 3, (B, Ht, Wt))
+    else:
+        sx, sy = (Ws - 1) / max(Wt - 1, 1), (Hs - 1) / max(Ht - 1, 1)
+        th = 0.07
+        gx = (np.cos(th) * xs * sx - np.sin(th) * ys * sy + 2.3)[None] + rs.uniform(-0.4, 0.4, (B, Ht, Wt))
+        gy = (np.sin(th) * xs * sx + np.cos(th) * ys * sy - 1.7)[None] + rs.uniform(-0.4, 0.4, (B, Ht, Wt))
+        if kind == "jump":                                   # a depth discontinuity: half the image lands elsewhere
+            gx[:, :, Wt // 2:] += 37.5
+            gy[:, Ht // 3:, :] -= 11.25
+    grid = np.stack([gx, gy], -1).astype(np.float32)
+    if grid.size > 40:
+        grid[0, 0, 0] = (np.nan, 1.0)
+        grid[0, -1, -1] = (1e9, -1e9)
+        grid[0, Ht // 2, Wt // 2] = (float(Ws - 1), float(Hs - 1))     # exact last row / column: zero weight
+    g = rs.uniform(-1, 1, (B, Ht, Wt, 1)).astype(np.float32)
+    mask = (rs.uniform(0, 1, (B, Ht, Wt)) > 0.2).astype(np.uint8)
+    gd, gg, gm = dev(grid), dev(g), dev(mask)
+
+    def reference(use_mask):
+        x, y = gd[..., 0], gd[..., 1]
+        fx, fy = torch.floor(x), torch.floor(y)
+        x0, x1 = fx.clamp(0, Ws - 1), (fx + 1).clamp(0, Ws - 1)
+        y0, y1 = fy.clamp(0, Hs - 1), (fy + 1).clamp(0, Hs - 1)
+        live = (x0 != x1) & (y0 != y1) & ~torch.isnan(x) & ~torch.isnan(y)
+        if use_mask:
+            live = live & (gm != 0)
+        v = torch.where(live, gg[..., 0], torch.zeros_like(x)).double()
+        wx0, wx1, wy0, wy1 = (x1 - x).double(), (x - x0).double(), (y1 - y).double(), (y - y0).double()
+        out = torch.zeros(B, Hs * Ws, dtype=torch.float64, device="cuda")
+        for xa, ya, w in ((x0, y0, wx0 * wy0), (x0, y1, wx0 * wy1), (x1, y0, wx1 * wy0), (x1, y1, wx1 * wy1)):
+            w = torch.where(live, w, torch.zeros_like(w))
+            idx = (torch.nan_to_num(ya) * Ws + torch.nan_to_num(xa)).long().reshape(B, -1)
+            out.scatter_add_(1, idx, (w * v).reshape(B, -1))
+        return out.reshape(B, Hs, Ws, 1)
+
+    old = ops.set_image_gradient_mode("ordered")
+    try:
+        for use_mask in (False, True):
+            m = gm if use_mask else None
+            ref = reference(use_mask)
+            scale = max(float(ref.abs().max()), 1e-30)
+            got = ops._bilinear_bwd_img(gg, gd, m, B, Hs, Ws, 1, Ht, Wt)
+            assert float((got.double() - ref).abs().max()) <= 2e-6 * scale, (kind, use_mask)
+            assert torch.equal(got, ops._bilinear_bwd_img(gg, gd, m, B, Hs, Ws, 1, Ht, Wt))   # same bits again
+            # the index built by its own entry point, then handed over as ready
+            idx = ops._tap_index_buffer(B, Hs, Ws, Ht, Wt, gd.device)
+            ops._check(ops._lib.fc3d_bilinear_tap_index(ops._stream(), gd.data_ptr(), m.data_ptr() if use_mask else None,
+                                                        B, Hs, Ws, Ht, Wt, idx.data_ptr()), "fc3d_bilinear_tap_index")
+            assert torch.equal(got, ops._bilinear_bwd_img(gg, gd, m, B, Hs, Ws, 1, Ht, Wt, index=idx))
+            ops.set_image_gradient_mode("atomic")
+            atom = ops._bilinear_bwd_img(gg, gd, m, B, Hs, Ws, 1, Ht, Wt)
+            ops.set_image_gradient_mode("ordered")
+            assert float((atom.double() - ref).abs().max()) <= 2e-6 * scale, (kind, use_mask)
+    finally:
+        ops.set_image_gradient_mode(old)
 
 
 def test_visible_mask_bit_exact(mods, golden):

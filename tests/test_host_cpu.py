@@ -21,14 +21,17 @@ def test_cabi_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in fc3d.h but not exported"
     assert declared == set(_native.SIGNATURES), declared ^ set(_native.SIGNATURES)
-    assert lib.fc3d_version() == 100
+    assert lib.fc3d_version() == 200
     assert lib.fc3d_status_string(-1).decode().startswith("invalid")
     # argument validation happens before any device work
     assert lib.fc3d_visible_mask(None, None, 1, 4, 4, 0, None, None) == -1
     # one 64-bit key per tile/strip of whichever kernel family has the most of them at this size:
     # 8 x 128 for the 64-column x 4-row wavefronts of the large-PSF kernels
     assert lib.fc3d_code_pattern_fwd_workspace(32, 512, 512) == 32 * 1024 * 8
-    assert lib.fc3d_bilinear_bwd_img_workspace(2, 64, 96, 1, 64, 96) == 2 * 24 * (16 + 1024 * 4)
+    # tap index: 8-byte boxes, per 512 target pixels one for the group, 4 for its runs, 32 for their segments
+    assert lib.fc3d_bilinear_bwd_img_workspace(2, 64, 96, 1, 64, 96) == 2 * 12 * 37 * 8
+    assert lib.fc3d_bilinear_bwd_img_workspace(2, 64, 96, 3, 64, 96) == 0            # one-channel images only
+    assert lib.fc3d_bilinear_bwd_img_workspace(1, 40000, 8, 1, 8, 8) == 0            # beyond the 16-bit box fields
     # the entry points around the path: one partial maximum per 4096 pixels (at most 256 per image),
     # one float4 partial per 256 pixels
     assert lib.fc3d_capture_post_workspace(32, 512, 512) == 32 * 64 * 4
