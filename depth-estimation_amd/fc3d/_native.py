@@ -9,7 +9,8 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libfc3d_hip.so")
+# FC3D_LIB_PATH: another build of the same library (kernel tuning experiments)
+LIB_PATH = os.environ.get("FC3D_LIB_PATH") or os.path.join(HERE, "libfc3d_hip.so")
 
 
 class LayerGrid(ctypes.Structure):

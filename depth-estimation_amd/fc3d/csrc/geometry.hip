@@ -278,7 +278,7 @@ __global__ __launch_bounds__(NT) void bilinear_bwd_grid_kernel(const float* __re
 //   stores the tile (not the apron) with plain 16-byte stores.  A tap that falls into the apron of
 //   one tile is added again by the tile that owns the cell, so every cell is written exactly once,
 //   by one wavefront, with every contribution in it.  A segment near a tile border is loaded by two
-//   or four wavefronts: at 64 x 16 tiles about 1.5 loads per sample, served by L2.
+//   or four wavefronts: at 64 x 12 tiles about 1.5 loads per sample, served by L2.
 //   LDS float atomics retire about one lane every three cycles on this chip, so the window is
 //   updated with plain read-add-write; lanes of one instruction that hit the same cell are
 //   serialised by an election through a byte-sized owner array.
@@ -498,8 +498,11 @@ __global__ __launch_bounds__(NT) void bilinear_tap_index_kernel(const float* __r
     emit_tap_index(tap_index_at(tap_index, B, gridDim.x, b), bx, by, on);
 }
 
+#ifndef FC3D_GDBG
+#define FC3D_GDBG 0          // timing experiments only: 1 no window adds, 2 no sampling at all, 4 no run / segment scans
+#endif
 #ifndef FC3D_GATHER_GY
-#define FC3D_GATHER_GY 16
+#define FC3D_GATHER_GY 12
 #endif
 constexpr int GX = 64, GY = FC3D_GATHER_GY;   // source tile of one wavefront
 constexpr int GWS = GX + 8;                   // window row stride: tile column 0 at window column 4 (16-byte aligned rows)
@@ -508,7 +511,11 @@ constexpr int G_GROUPS = NT * 2;              // group boxes the workgroup scans
 constexpr int G_UNROLL = 2;                   // run-level steps (64 boxes each) whose loads are in flight together
 constexpr int G_RUNS = 64 + 64 * G_UNROLL;    // run list: handed on above 64 entries, one round adds at most 64 * G_UNROLL
 constexpr int G_CAND = 128;                   // candidate segments: drained above 64, one step adds at most 64
-constexpr int G_DEPTH = 8;                    // sample steps whose loads are in flight together
+constexpr int G_SEGU = 4;                     // segment-level steps whose loads are in flight together
+#ifndef FC3D_GATHER_DEPTH
+#define FC3D_GATHER_DEPTH 4
+#endif
+constexpr int G_DEPTH = FC3D_GATHER_DEPTH;    // sample steps whose loads are in flight together
 constexpr int G_OWN = 256;                    // election slots (cells hash onto them)
 
 struct GatherSample {
@@ -546,6 +553,56 @@ __device__ __forceinline__ void window_add4_hashed(lds_vfloat win, lds_vu8 own, 
     } while (__builtin_expect(__ballot(pend) != 0, 0));
 }
 
+// The first n candidate segments (ids in cand[], live bits in cbits[]) are sampled and their taps added
+// to the window, 64 / SEG segments per step; the loads of G_DEPTH steps are issued together so that
+// one memory latency covers them all.  A real function (not inlined): the scans call it from
+// several places.
+// A live sample's corners were not clamped: x0 = floor x, x1 = x0 + 1, and the weights are those
+// of make_taps (x1 - x, x - x0; the corners are exact in fp32).
+struct GatherTile {
+    float fbx0, fbx1, fby0, fby1;     // base cells whose taps reach the tile
+    float fcol0;                      // source column of window column 0
+};
+__device__ __noinline__ void gather_drain(const float2* __restrict__ gb, const float* __restrict__ vb, unsigned HWt,
+                                          lds_vfloat win, lds_vu8 own, lds_vint cand, lds_vint cbits, int n,
+                                          GatherTile tl) {
+    constexpr int STEP = 64 / SEG;
+    const int lane = threadIdx.x & 63;
+    for (int e0 = 0; e0 < n; e0 += STEP * G_DEPTH) {
+        GatherSample sm[G_DEPTH];
+#pragma unroll
+        for (int d = 0; d < G_DEPTH; ++d) {
+            const int e = e0 + d * STEP;
+            if (e < n) {
+                const int j = min(e + (lane >> 4), n - 1);
+                const int seg = cand[j], bits = cbits[j];
+                const unsigned p = (unsigned)seg * SEG + (lane & 15);
+                sm[d].live = (e + (lane >> 4) < n) && ((bits >> (lane & 15)) & 1);   // a live pixel lies inside the target image
+                const unsigned q = min(p, HWt - 1u);
+                sm[d].g = ld_at(gb, q);
+                sm[d].v = ld_at(vb, q);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < G_DEPTH; ++d) {
+            if (e0 + d * STEP < n) {
+                const float gx = sm[d].g.x, gy = sm[d].g.y, v = sm[d].v;
+                const float fx = floorf(gx), fy = floorf(gy);
+                const bool on = sm[d].live && fx >= tl.fbx0 && fx <= tl.fbx1 && fy >= tl.fby0 && fy <= tl.fby1;
+                const float wx1 = __fsub_rn(gx, fx), wx0 = __fsub_rn(__fadd_rn(fx, 1.0f), gx);
+                const float wy1 = __fsub_rn(gy, fy), wy0 = __fsub_rn(__fadd_rn(fy, 1.0f), gy);
+                const int c = on ? (int)(__fsub_rn(fy, tl.fby0) * (float)GWS + __fsub_rn(fx, tl.fcol0)) : 0;
+#if FC3D_GDBG & 1
+                if (on && v == 123.456f) win[c] = wx0 * wy0 + wx1 * wy1;
+#else
+                window_add4_hashed(win, own, c, GWS, (wx0 * wy0) * v, (wx1 * wy0) * v, (wx0 * wy1) * v, (wx1 * wy1) * v, on,
+                                   lane);
+#endif
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(NT) void bilinear_bwd_img_gather_kernel(
     const float* __restrict__ g_out, const float* __restrict__ grid, void* __restrict__ tap_index, int B, int groups,
     int Hs, int Ws, unsigned HWt, float* __restrict__ g_img) {
@@ -563,7 +620,6 @@ __global__ __launch_bounds__(NT) void bilinear_bwd_img_gather_kernel(
     // base cells whose taps reach the workgroup's tiles / this wavefront's tile
     const int rbx0 = rx0 - 1, rbx1 = rx0 + (NT / 64) * GX - 1, by0 = sy0 - 1, by1 = sy0 + GY - 1;
     const int bx0 = sx0 - 1, bx1 = sx0 + GX - 1;
-    const float fbx0 = (float)bx0, fbx1 = (float)bx1, fby0 = (float)by0, fby1 = (float)by1;
     const TapIndex ix = tap_index_at(tap_index, B, groups, b);
     const float2* gb = reinterpret_cast<const float2*>(grid) + (long)b * HWt;
     const float* vb = g_out + (long)b * HWt;
@@ -576,41 +632,18 @@ __global__ __launch_bounds__(NT) void bilinear_bwd_img_gather_kernel(
         for (int i = lane; i < GWR * GWS / 4; i += 64) w4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 
-    auto fetch = [&](int e, int n) -> GatherSample {     // entry e of the candidate list, this lane's pixel of it
-        GatherSample sm;
-        const int j = min(e + (lane >> 4), n - 1);
-        const int seg = cand[j], bits = cbits[j];
-        const unsigned p = (unsigned)seg * SEG + (lane & 15);
-        sm.live = (e + (lane >> 4) < n) && ((bits >> (lane & 15)) & 1);      // a live pixel lies inside the target image
-        const unsigned q = min(p, HWt - 1u);
-        sm.g = ld_at(gb, q);
-        sm.v = ld_at(vb, q);
-        return sm;
-    };
-    // A live sample's corners were not clamped: x0 = floor x, x1 = x0 + 1, and the weights are those
-    // of make_taps (x1 - x, x - x0; the corners are exact in fp32).
-    auto add = [&](const GatherSample& sm) {
-        const float fx = floorf(sm.g.x), fy = floorf(sm.g.y);
-        const bool on = sm.live && fx >= fbx0 && fx <= fbx1 && fy >= fby0 && fy <= fby1;
-        const float wx1 = __fsub_rn(sm.g.x, fx), wx0 = __fsub_rn(__fadd_rn(fx, 1.0f), sm.g.x);
-        const float wy1 = __fsub_rn(sm.g.y, fy), wy0 = __fsub_rn(__fadd_rn(fy, 1.0f), sm.g.y);
-        const int c = on ? (int)(__fsub_rn(fy, fby0) * (float)GWS + __fsub_rn(fx, (float)(sx0 - 4))) : 0;
-        window_add4_hashed(win, own, c, GWS, (wx0 * wy0) * sm.v, (wx1 * wy0) * sm.v, (wx0 * wy1) * sm.v,
-                           (wx1 * wy1) * sm.v, on, lane);
-    };
-    // the first n candidate segments, 64 / SEG per step; the loads of G_DEPTH steps are issued
-    // together so that one memory latency covers them all
-    auto drain = [&](int n) {
-        constexpr int STEP = 64 / SEG;
-        for (int e0 = 0; e0 < n; e0 += STEP * G_DEPTH) {
-            GatherSample sm[G_DEPTH];
-#pragma unroll
-            for (int d = 0; d < G_DEPTH; ++d)
-                if (e0 + d * STEP < n) sm[d] = fetch(e0 + d * STEP, n);
-#pragma unroll
-            for (int d = 0; d < G_DEPTH; ++d)
-                if (e0 + d * STEP < n) add(sm[d]);
-        }
+    GatherTile tl;
+    tl.fbx0 = (float)bx0; tl.fbx1 = (float)bx1; tl.fby0 = (float)by0; tl.fby1 = (float)by1; tl.fcol0 = (float)(sx0 - 4);
+    // hands the first m candidates to gather_drain and moves the rest (fewer than 64) to the front
+    auto drain_front = [&](int& ncand, int m) {
+#if !(FC3D_GDBG & 2)
+        if (m > 0) gather_drain(gb, vb, HWt, win, own, cand, cbits, m, tl);
+#endif
+        const int rest = ncand - m;
+        int keep_s = 0, keep_b = 0;
+        if (lane < rest) { keep_s = cand[m + lane]; keep_b = cbits[m + lane]; }
+        if (lane < rest) { cand[lane] = keep_s; cbits[lane] = keep_b; }
+        ncand = rest;
     };
 
     // Three nested scans, each filling a list that the next level consumes: groups (scanned by the
@@ -633,7 +666,7 @@ __global__ __launch_bounds__(NT) void bilinear_bwd_img_gather_kernel(
         }
         if (lane == 0) s_ng[wv] = cnt;
         __syncthreads();
-        if (tile_live) {
+        if (tile_live && !(FC3D_GDBG & 4)) {
             int off[NT / 64 + 1];
             off[0] = 0;
 #pragma unroll
@@ -664,27 +697,26 @@ __global__ __launch_bounds__(NT) void bilinear_bwd_img_gather_kernel(
                     }
                 }
                 if (nr <= 64 && !fin_r) continue;
-                const int rounds_s = (nr + RPS - 1) / RPS;
-                for (int rs = 0; rs <= rounds_s; ++rs) {
-                    const bool fin_s = rs == rounds_s;
-                    if (!fin_s) {
-                        const int j = rs * RPS + lane / SEG_PER_RUN;
-                        const int seg = rhit[min(j, nr - 1)] * SEG_PER_RUN + lane % SEG_PER_RUN;
-                        const int2 sb = ix.seg[seg];
-                        const bool hit = j < nr && seg_meets(sb, bx0, bx1, by0, by1);
-                        list_append(cbits, ncand, hit, (int)((unsigned)sb.y >> 16), lane);
-                        ncand = list_append(cand, ncand, hit, seg, lane);
+                const int rounds_s = (nr + RPS * G_SEGU - 1) / (RPS * G_SEGU);
+                for (int rs = 0; rs < rounds_s; ++rs) {
+                    int seg[G_SEGU];
+                    int2 sb[G_SEGU];
+#pragma unroll
+                    for (int u = 0; u < G_SEGU; ++u) {
+                        const int j = (rs * G_SEGU + u) * RPS + lane / SEG_PER_RUN;
+                        seg[u] = rhit[min(j, nr - 1)] * SEG_PER_RUN + lane % SEG_PER_RUN;
+                        sb[u] = ix.seg[seg[u]];
                     }
-                    const bool last = fin_g && fin_r && fin_s;
-                    if (ncand <= 64 && !last) continue;
-                    const int m = last ? ncand : 64;
-                    if (m > 0) drain(m);
-                    const int rest = ncand - m;                  // < 64
-                    int keep_s = 0, keep_b = 0;
-                    if (lane < rest) { keep_s = cand[m + lane]; keep_b = cbits[m + lane]; }
-                    if (lane < rest) { cand[lane] = keep_s; cbits[lane] = keep_b; }
-                    ncand = rest;
+#pragma unroll
+                    for (int u = 0; u < G_SEGU; ++u) {
+                        const int j = (rs * G_SEGU + u) * RPS + lane / SEG_PER_RUN;
+                        const bool hit = j < nr && seg_meets(sb[u], bx0, bx1, by0, by1);
+                        list_append(cbits, ncand, hit, (int)((unsigned)sb[u].y >> 16), lane);
+                        ncand = list_append(cand, ncand, hit, seg[u], lane);
+                        if (ncand > 64) drain_front(ncand, 64);
+                    }
                 }
+                if (fin_g && fin_r) drain_front(ncand, ncand);
                 nr = 0;
             }
         }

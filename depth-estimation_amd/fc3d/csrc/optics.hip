@@ -511,20 +511,23 @@ __device__ __forceinline__ void stage_psf_stack(float* __restrict__ wts, const f
 template <int K, int R>
 __global__ __launch_bounds__(NT) void code_pattern_bwd_roll_kernel(
     const float* __restrict__ g, const float* __restrict__ out, const uint8_t* __restrict__ layer_u8,
-    const float* __restrict__ max_in, const float* __restrict__ psf, int H, int W, int L,
+    const float* __restrict__ max_in, const float* __restrict__ psf, int H, int W, int L, int nstrips,
     float* __restrict__ partial, float* __restrict__ g_pat0) {
     constexpr int PAD = Roll<K>::PAD, SW = Roll<K>::SW, KKP = Roll<K>::KKP;
     constexpr int NR = R + K - 1;                 // source rows a strip reads
     extern __shared__ float smem[];               // [L][KKP]
-    const int b = blockIdx.z;
+    const int b = blockIdx.y;
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const long img = (long)b * H * W;
 
-    const int strip = blockIdx.x * (NT / 64) + wv;
-    const long pidx = ((long)b * gridDim.y + blockIdx.y) * (gridDim.x * (NT / 64)) + strip;
+    // (row block, strip) pairs are numbered along one grid axis, so that only the last workgroup
+    // of an image can hold wavefronts without work
+    const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * (NT / 64) + wv);   // the same for all lanes: keep it scalar
+    const long pidx = (long)b * (gridDim.x * (NT / 64)) + wid;
+    const int strip = wid % nstrips;
     const int xs = strip * SW;                    // first output column of this wavefront's strip
     const int x = xs - PAD + lane;
-    const int y0 = blockIdx.y * R;
+    const int y0 = (wid / nstrips) * R;
     const bool colok = x >= 0 && x < W;
     const int xc = min(max(x, 0), W - 1);
     const float* gi = g + img;              // uniform 64-bit bases + 32-bit per-lane offsets
@@ -548,7 +551,7 @@ __global__ __launch_bounds__(NT) void code_pattern_bwd_roll_kernel(
     const float rden = 1.0f / den;
     stage_psf_stack<K>(smem, psf, L);
     __syncthreads();
-    if (xs >= W) {
+    if (y0 >= H) {
         if (lane == 0) partial[pidx] = 0.0f;
         return;
     }
@@ -642,19 +645,21 @@ template <int K, int R>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(Roll<K>::FWD_WAVES, Roll<K>::FWD_WAVES)))
 void code_pattern_fwd_roll_kernel(
     const float* __restrict__ pat0, long sb, long sh, long sw, const float* __restrict__ z,
-    const float* __restrict__ psf, int H, int W, fc3d_layer_grid lg, float* __restrict__ raw,
+    const float* __restrict__ psf, int H, int W, int nstrips, fc3d_layer_grid lg, float* __restrict__ raw,
     uint8_t* __restrict__ layer_u8, unsigned long long* __restrict__ tilekey) {
     constexpr int PAD = Roll<K>::PAD, SW = Roll<K>::SW, KKP = Roll<K>::KKP;
     constexpr int NR = R + K - 1;
     extern __shared__ float smem[];               // [L][KKP]
-    const int b = blockIdx.z;
+    const int b = blockIdx.y;
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const long img = (long)b * H * W;
-    const int strip = blockIdx.x * (NT / 64) + wv;
-    const long kidx = ((long)b * gridDim.y + blockIdx.y) * (gridDim.x * (NT / 64)) + strip;
+    // (row block, strip) pairs along one grid axis: no idle strips; the same for all lanes, so kept scalar
+    const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * (NT / 64) + wv);
+    const long kidx = (long)b * (gridDim.x * (NT / 64)) + wid;
+    const int strip = wid % nstrips;
     const int xs = strip * SW;
     const int x = xs - PAD + lane;
-    const int y0 = blockIdx.y * R;
+    const int y0 = (wid / nstrips) * R;
     const bool colok = x >= 0 && x < W;
     const bool mine = lane >= PAD && lane < 64 - PAD && x < W;   // columns this lane writes
     const int xc = min(max(x, 0), W - 1);
@@ -673,7 +678,7 @@ void code_pattern_fwd_roll_kernel(
     const LayerFast lfast = layer_fast_setup(lg);
     stage_psf_stack<K>(smem, psf, lg.n_layers);   // after the loads above were issued: the latencies overlap
     __syncthreads();
-    if (xs >= W) {
+    if (y0 >= H) {
         if (lane == 0) tilekey[kidx] = 0ull;      // below every real key
         return;
     }
@@ -1279,10 +1284,11 @@ extern "C" int fc3d_code_pattern_fwd(void* stream, const float* pat0, int64_t pa
     if (Kw == KV) {                                                                                              \
         const size_t rlds = (size_t)grid.n_layers * Roll<KV>::KKP * sizeof(float);                               \
         if (int e = allow_big_lds(code_pattern_fwd_roll_kernel<KV, RR>, rlds)) return e;                  \
-        const dim3 gr(cdiv(cdiv(W, Roll<KV>::SW), NT / 64), cdiv(H, RR), B);                              \
-        *keys_per_image = (int)(gr.x * (NT / 64) * gr.y);                                                        \
-        FC3D_LAUNCH("code_pattern_fwd", (code_pattern_fwd_roll_kernel<KV, RR>), gr, blk, rlds, s, pat0,   \
-                    (long)pat_sb, (long)pat_sh, (long)pat_sw, z, psf, H, W, grid, raw_out, layer_u8,             \
+        const int nstrips = cdiv(W, Roll<KV>::SW);                                                               \
+        const dim3 gr(cdiv((long)nstrips * cdiv(H, RR), NT / 64), B);                                            \
+        *keys_per_image = (int)(gr.x * (NT / 64));                                                               \
+        FC3D_LAUNCH("code_pattern_fwd", (code_pattern_fwd_roll_kernel<KV, RR>), gr, blk, rlds, s, pat0,          \
+                    (long)pat_sb, (long)pat_sh, (long)pat_sw, z, psf, H, W, nstrips, grid, raw_out, layer_u8,    \
                     (unsigned long long*)tilekey_u64);                                                           \
         return FC3D_OK;                                                                                          \
     }
@@ -1377,11 +1383,12 @@ extern "C" int fc3d_code_pattern_bwd(void* stream, const float* g_out, const flo
     if (Kw == KV) {                                                                                              \
         const size_t rlds = (size_t)L * Roll<KV>::KKP * sizeof(float);                                           \
         if (int e = allow_big_lds(code_pattern_bwd_roll_kernel<KV, R>, rlds)) return e;                          \
-        const dim3 gr(cdiv(cdiv(W, Roll<KV>::SW), NT / 64), cdiv(H, R), B);                                      \
+        const int nstrips = cdiv(W, Roll<KV>::SW);                                                               \
+        const dim3 gr(cdiv((long)nstrips * cdiv(H, R), NT / 64), B);                                             \
         FC3D_LAUNCH("code_pattern_bwd", (code_pattern_bwd_roll_kernel<KV, R>), gr, dim3(NT), rlds, s, g_out,     \
-                    out, layer_u8, max_in, psf, H, W, L, partial, g_pat0);                                       \
+                    out, layer_u8, max_in, psf, H, W, L, nstrips, partial, g_pat0);                              \
         FC3D_LAUNCH("code_pattern_bwd_max", code_pattern_bwd_max_kernel, dim3(B), dim3(NT), 0, s,                \
-                    (const float*)partial, (int)(gr.x * (NT / 64) * gr.y), max_in, argmax_i32, layer_u8, psf, H, \
+                    (const float*)partial, (int)(gr.x * (NT / 64)), max_in, argmax_i32, layer_u8, psf, H,        \
                     W, KV, g_pat0);                                                                              \
         return FC3D_OK;                                                                                          \
     }

@@ -149,7 +149,7 @@ int fc3d_bilinear_bwd_grid(void *stream, const float *g_out, const float *img, c
 /* d out / d img (the backward of the index gathers at geometry_pytorch.py:166-169: a scatter-add of
  * the four weighted taps), written -- not accumulated -- to g_img [B][Hs][Ws][C].
  * C == 1 with `index` (fc3d_bilinear_bwd_img_workspace() bytes, 8-byte aligned): gather form.  Every
- * wavefront owns a 64x16 tile of the SOURCE image, finds through the tap index the target pixels
+ * wavefront owns a 64x12 tile of the SOURCE image, finds through the tap index the target pixels
  * that can touch it, sums their taps in LDS and stores the tile once: no atomics, no zero fill, a
  * fixed summation order (bit-reproducible).  The tap index (two levels of boxes that say where runs
  * of target pixels landed) is built by the call itself when index_ready == 0; fc3d_warp_p2c_fwd can
