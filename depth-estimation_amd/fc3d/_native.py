@@ -37,6 +37,8 @@ SIGNATURES = {
     "fc3d_pose_transforms": (c_int, [P, P, P, I64, c_int, P, P, P, P, c_size_t]),
     "fc3d_project_fwd": (c_int, [P, P, I64, I64, I64, I64, P, c_int, c_int, c_int, P]),
     "fc3d_project_bwd": (c_int, [P, P, P, I64, I64, I64, I64, P, c_int, c_int, c_int, P]),
+    "fc3d_project_bwd_transform_workspace": (c_size_t, [c_int, c_int, c_int]),
+    "fc3d_project_bwd_transform": (c_int, [P, P, P, I64, I64, I64, I64, P, c_int, c_int, c_int, P, P]),
     "fc3d_bilinear_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "fc3d_bilinear_bwd_grid": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "fc3d_bilinear_bwd_img_workspace": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),

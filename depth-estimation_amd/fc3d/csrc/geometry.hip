@@ -1114,6 +1114,80 @@ __global__ __launch_bounds__(NT) void project_bwd_kernel(const float* __restrict
     }
 }
 
+// Backward of coord_transform w.r.t. the transform (torch.matmul(transform, coord) is differentiable
+// in both arguments, geometry_pytorch.py:79): g_T[i][k] = sum over pixels of g_u[i] * coord[k] for
+// the three rows that reach the output (row 3 gets zero).  One partial of the twelve sums per
+// workgroup (wavefront shuffles, then the workgroup's wavefronts in order), added up in index order
+// with double accumulators by project_bwd_transform_sum_kernel: reproducible, no atomics.
+template <int LAYOUT, bool FMA>
+__global__ __launch_bounds__(NT) void project_bwd_transform_kernel(const float* __restrict__ g_grid,
+                                                                   const float* __restrict__ coord, long sb, long sc,
+                                                                   long sh, long sw, const float* __restrict__ Tm, int H,
+                                                                   int W, float* __restrict__ partial) {
+    __shared__ float s_part[NT / 64][12];
+    const int b = blockIdx.y;
+    const long HW = (long)H * W;
+    const long p0 = lane_first_pixel();
+    const float* T = Tm + (long)b * 16;
+    const float* cb = coord + (long)b * sb;
+    const float2* gg = reinterpret_cast<const float2*>(g_grid) + (long)b * HW;
+    float acc[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc[k] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < PPL; ++i) {
+        const long p = p0 + 64 * i;
+        if (p >= HW) continue;
+        float c[4];
+        load_coord<LAYOUT>(cb, sc, sh, sw, p, W, c);
+        const float xu = row_dot<FMA>(T + 0, c[0], c[1], c[2], c[3]);
+        const float yu = row_dot<FMA>(T + 4, c[0], c[1], c[2], c[3]);
+        const float zu = row_dot<FMA>(T + 8, c[0], c[1], c[2], c[3]);
+        const float den = zu + 1e-10f;
+        const float2 g = gg[p];
+        const float gu[3] = {g.x / den, g.y / den, -(g.x * xu + g.y * yu) / (den * den)};
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[r * 4 + k] = fmaf(gu[r], c[k], acc[r * 4 + k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc[k] = wave_sum(acc[k]);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) s_part[threadIdx.x >> 6][k] = acc[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 12) {
+        float t = s_part[0][threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < NT / 64; ++w) t += s_part[w][threadIdx.x];
+        partial[((long)b * gridDim.x + blockIdx.x) * 12 + threadIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(NT) void project_bwd_transform_sum_kernel(const float* __restrict__ partial, int nblk,
+                                                                       float* __restrict__ g_T) {
+    __shared__ double s_red[NT / 64];
+    const int b = blockIdx.x;
+    const float* pb = partial + (long)b * nblk * 12;
+    for (int k = 0; k < 12; ++k) {
+        double s = 0.0;
+        for (int i = threadIdx.x; i < nblk; i += NT) s += (double)pb[(long)i * 12 + k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = s_red[0];
+            for (int w = 1; w < NT / 64; ++w) t += s_red[w];
+            g_T[(long)b * 16 + k] = (float)t;
+        }
+    }
+    if (threadIdx.x < 4) g_T[(long)b * 16 + 12 + threadIdx.x] = 0.0f;
+}
+
 // ---------------------------------------------------------------------------------------
 // host helpers
 // ---------------------------------------------------------------------------------------
@@ -1189,6 +1263,30 @@ extern "C" int fc3d_project_bwd(void* stream, const float* g_grid, const float* 
     FC3D_DISPATCH_LAYOUT("project_bwd", project_bwd_kernel, layout, fma);
 #undef ARGS
     FC3D_LAUNCH_CHECK();
+    return FC3D_OK;
+}
+
+extern "C" size_t fc3d_project_bwd_transform_workspace(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)B * cdiv((long)H * W, PX_PER_BLOCK) * 12 * sizeof(float);
+}
+
+extern "C" int fc3d_project_bwd_transform(void* stream, const float* g_grid, const float* coord, int64_t sb, int64_t sc,
+                                          int64_t sh, int64_t sw, const float* T, int B, int H, int W, void* workspace,
+                                          float* g_T) {
+    if (!g_grid || !coord || !T || !workspace || !g_T) return FC3D_EINVAL;
+    if (int e = check_img(B, H, W)) return e;
+    if (!aligned4(coord) || !aligned4(workspace) || (reinterpret_cast<uintptr_t>(g_grid) & 7u)) return FC3D_EALIGN;
+    const int layout = pick_layout(coord, sc, sh, sw, W);
+    const bool fma = use_fma(H, W);
+    dim3 g(cdiv((long)H * W, PX_PER_BLOCK), B), blk(NT);
+    hipStream_t s = (hipStream_t)stream;
+    float* partial = (float*)workspace;
+#define ARGS g_grid, coord, (long)sb, (long)sc, (long)sh, (long)sw, T, H, W, partial
+    FC3D_DISPATCH_LAYOUT("project_bwd_transform", project_bwd_transform_kernel, layout, fma);
+#undef ARGS
+    FC3D_LAUNCH("project_bwd_transform_sum", project_bwd_transform_sum_kernel, dim3(B), blk, 0, s, (const float*)partial,
+                (int)g.x, g_T);
     return FC3D_OK;
 }
 

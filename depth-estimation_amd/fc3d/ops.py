@@ -208,16 +208,54 @@ class ProjectFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_grid):
         coord, T = ctx.saved_tensors
-        if ctx.needs_input_grad[1]:
-            raise NotImplementedError("gradient w.r.t. the pose/transform of coord_transform is not implemented")
         B, _, H, W = coord.shape
         g = _dense(g_grid)
         st = coord.stride()
-        gc = torch.empty((B, 4, H, W), dtype=torch.float32, device=g.device)
+        gc = gT = None
         with _on_device(g.device):
-            _check(_lib.fc3d_project_bwd(_stream(), g.data_ptr(), coord.data_ptr(), st[0], st[1], st[2], st[3],
-                                         T.data_ptr(), B, H, W, gc.data_ptr()), "fc3d_project_bwd")
-        return gc, None
+            if ctx.needs_input_grad[0]:
+                gc = torch.empty((B, 4, H, W), dtype=torch.float32, device=g.device)
+                _check(_lib.fc3d_project_bwd(_stream(), g.data_ptr(), coord.data_ptr(), st[0], st[1], st[2], st[3],
+                                             T.data_ptr(), B, H, W, gc.data_ptr()), "fc3d_project_bwd")
+            if ctx.needs_input_grad[1]:
+                ws = torch.empty(max(1, _lib.fc3d_project_bwd_transform_workspace(B, H, W) // 4), dtype=torch.float32,
+                                 device=g.device)
+                gT = torch.empty((B, 4, 4), dtype=torch.float32, device=g.device)
+                _check(_lib.fc3d_project_bwd_transform(_stream(), g.data_ptr(), coord.data_ptr(), st[0], st[1], st[2],
+                                                       st[3], T.data_ptr(), B, H, W, ws.data_ptr(), gT.data_ptr()),
+                       "fc3d_project_bwd_transform")
+        return gc, gT
+
+
+class PoseTransformsFn(torch.autograd.Function):
+    """(K@pose, K@inverse(pose), inverse(pose)) with gradients w.r.t. the pose (K is data): the
+    forward values are those of pose_transforms; the backward is three batched 4x4 products,
+    g_pose = K^T g_fwd - A^T (g_A + K^T g_inv) A^T with A = inverse(pose) (the gradient of a matrix
+    inverse), evaluated with tensor ops on the [B,4,4] matrices."""
+
+    @staticmethod
+    def forward(ctx, pose, K):
+        tf, ti, a = pose_transforms(pose, K, want_fwd=True, want_inv=True, want_a=True)
+        Kb = K if K.dim() == 3 else K.unsqueeze(0)
+        ctx.save_for_backward(a, Kb)
+        ctx.set_materialize_grads(False)
+        return tf, ti, a
+
+    @staticmethod
+    def backward(ctx, g_tf, g_ti, g_a):
+        a, Kb = ctx.saved_tensors
+        Kt = Kb.transpose(1, 2)
+        gp = None
+        if g_tf is not None:
+            gp = Kt @ g_tf
+        ga = g_a
+        if g_ti is not None:
+            ga = Kt @ g_ti if ga is None else ga + Kt @ g_ti
+        if ga is not None:
+            at = a.transpose(1, 2)
+            term = -(at @ ga @ at)
+            gp = term if gp is None else gp + term
+        return gp, None
 
 
 _IMG_GRAD_MODE = "ordered"

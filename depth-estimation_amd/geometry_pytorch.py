@@ -12,8 +12,9 @@ Differences a caller can observe:
     in fp32, so grids that involve the inverse can differ in the last bit;
   * bilinear_sampler indexes with integers; the reference builds flat indices
     in fp32, which goes wrong once B*H*W exceeds 2**24 (B > 64 at 512x512);
-  * gradients w.r.t. poses / intrinsics are not implemented (they are data in
-    the capture simulator); asking for them raises NotImplementedError.
+  * the gradient w.r.t. the pose is implemented for coord_transform,
+    coord0TOgrid1 and warp_p2c; zp_cView_to_zc raises NotImplementedError for
+    it, and intrinsics are constants as in the reference.
 """
 from __future__ import annotations
 
@@ -136,12 +137,13 @@ def coord_transform(coord, transform):
 
 def coord0TOgrid1(coord0, pose01):
     """Scene points of view 0 -> pixel coordinates in view 1 (geometry_pytorch.py:93-106)."""
-    if pose01.requires_grad and torch.is_grad_enabled():
-        raise NotImplementedError("coord0TOgrid1: gradient w.r.t. the pose is not implemented")
     if coord0.shape[0] == 0:
         return coord0.new_zeros((0, coord0.shape[2], coord0.shape[3], 2))
     K = _intrinsics_for(coord0.shape[0], coord0.device)
-    T, _, _ = _ops.pose_transforms(pose01.detach(), K, want_fwd=True)
+    if pose01.requires_grad and torch.is_grad_enabled():
+        T, _, _ = _ops.PoseTransformsFn.apply(pose01, K)       # K @ pose with the gradient K^T g
+    else:
+        T, _, _ = _ops.pose_transforms(pose01.detach(), K, want_fwd=True)
     return _ops.ProjectFn.apply(coord0, T)
 
 
@@ -181,10 +183,11 @@ def warp_p2c(Ip, coord_p, coord_c, pose_p2c):
         return Ip.clone(), e, e.clone()
     if torch.is_grad_enabled() and (coord_p.requires_grad or coord_c.requires_grad or pose_p2c.requires_grad):
         # rare differentiable-geometry case: compose the individual operators
-        if pose_p2c.requires_grad:
-            raise NotImplementedError("warp_p2c: gradient w.r.t. the pose is not implemented")
         K = _intrinsics_for(coord_p.shape[0], coord_p.device)
-        T_p2c, T_c2p, _ = _ops.pose_transforms(pose_p2c, K, want_fwd=True, want_inv=True)
+        if pose_p2c.requires_grad:
+            T_p2c, T_c2p, _ = _ops.PoseTransformsFn.apply(pose_p2c, K)
+        else:
+            T_p2c, T_c2p, _ = _ops.pose_transforms(pose_p2c, K, want_fwd=True, want_inv=True)
         grid_c2p = _ops.ProjectFn.apply(coord_c, T_c2p)
         Ic = _ops.BilinearFn.apply(Ip, grid_c2p)
         grid_p2c = _ops.ProjectFn.apply(coord_p, T_p2c)

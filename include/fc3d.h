@@ -135,6 +135,16 @@ int fc3d_project_fwd(void *stream, const float *coord, int64_t sb, int64_t sc, i
 int fc3d_project_bwd(void *stream, const float *g_grid, const float *coord, int64_t sb, int64_t sc,
                      int64_t sh, int64_t sw, const float *T, int B, int H, int W, float *g_coord);
 
+/* Backward of the same product w.r.t. the transform (torch.matmul is differentiable in both
+ * arguments, geometry_pytorch.py:79): g_T [B][16], g_T[i][k] = sum over pixels of g_u[i]*coord[k]
+ * for rows 0..2, row 3 zero.  workspace: fc3d_project_bwd_transform_workspace bytes (one partial of
+ * the twelve sums per 512 pixels, added in a fixed order: reproducible).  The gradient w.r.t. a pose
+ * behind T = K*pose is K^T g_T (coord0TOgrid1, :103-104).                                        */
+size_t fc3d_project_bwd_transform_workspace(int B, int H, int W);
+int fc3d_project_bwd_transform(void *stream, const float *g_grid, const float *coord, int64_t sb, int64_t sc,
+                               int64_t sh, int64_t sw, const float *T, int B, int H, int W, void *workspace,
+                               float *g_T);
+
 /* bilinear_sampler, geometry_pytorch.py:109-177.  img [B][Hs][Ws][C],
  * grid [B][Ht][Wt][2] -> out [B][Ht][Wt][C].  mask_u8 [B][Ht][Wt] (may be NULL)
  * multiplies the result (the compositing step of warp_p2c, :279).             */

@@ -218,10 +218,14 @@ def test_project_bit_exact(mods, golden, monkeypatch):
     pose = dev(g["pose"])
     monkeypatch.setattr(G, "get_intrinsic", patched_K(float(g["cx"]), float(g["cy"])))
     c = coord.clone().requires_grad_(True)
-    grid = G.coord0TOgrid1(c, pose)
+    pg = pose.clone().requires_grad_(True)
+    grid = G.coord0TOgrid1(c, pg)
     grid.backward(dev(g["g_grid"]))
     assert np.array_equal(grid.detach().cpu().numpy(), g["grid"])
     assert rel_err(c.grad.cpu().numpy(), g["grad_coord"]) < TOL
+    assert rel_err(pg.grad.cpu().numpy(), g["grad_pose"]) < TOL        # K^T (sum over pixels of g_u x coord)
+    for b in range(pg.shape[0]):                                       # ... and per sample, entry by entry
+        assert np.allclose(pg.grad[b].cpu().numpy(), g["grad_pose"][b], rtol=1e-3, atol=1e-4 * np.abs(g["grad_pose"][b]).max())
     monkeypatch.undo()
     assert np.array_equal(G.coord0TOgrid1(coord, pose).cpu().numpy(), g["grid_native"])
     # permuted [B,H,W,4] view (what z2pointcloud hands over) gives the same bits
@@ -234,10 +238,17 @@ def test_project_bit_exact(mods, golden, monkeypatch):
     assert np.array_equal(G.coord0TOgrid1(odd, pose).cpu().numpy(), g["grid_native"])
     # arbitrary matrices through coord_transform
     cr = dev(g["coord_r"]).requires_grad_(True)
-    gr = G.coord_transform(cr, dev(g["tr"]))
+    trg = dev(g["tr"]).requires_grad_(True)
+    gr = G.coord_transform(cr, trg)
     gr.backward(dev(g["g_grid_r"]))
     assert np.array_equal(gr.detach().cpu().numpy(), g["grid_r"])
     assert rel_err(cr.grad.cpu().numpy(), g["grad_coord_r"]) < TOL
+    assert rel_err(trg.grad.cpu().numpy(), g["grad_tr"]) < TOL
+    # only the transform asks for a gradient; a strided view of the points
+    trg2 = dev(g["tr"]).requires_grad_(True)
+    inter_r = dev(g["coord_r"]).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    G.coord_transform(inter_r, trg2).backward(dev(g["g_grid_r"]))
+    assert torch.equal(trg2.grad, trg.grad)
     # tiny image: torch switches to its unfused small-matrix product below 25 pixels
     tiny = dev(g["coord_r"][:, :, :4, :5])
     ref = orc.coord_transform(t(g["coord_r"][:, :, :4, :5]), t(g["tr"]))
@@ -443,6 +454,20 @@ def test_warp_differentiable_geometry_path(mods, golden, monkeypatch):
     assert rel_err(Ic.detach().cpu().numpy(), g["Ic"]) < TOL
     assert rel_err(ip.grad.cpu().numpy(), g["grad_Ip"]) < TOL
     assert zc.grad is not None and torch.isfinite(zc.grad).all()
+    # the pose as a differentiable input (through K @ pose and K @ inverse(pose)) against the oracle's
+    # autograd on the CPU; the image is smooth here so that the bilinear weights' gradient is well defined
+    orc = mods["orc"]
+    ys, xs = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    smooth = (0.5 + 0.3 * np.sin(xs / 7.0) * np.cos(ys / 5.0)).astype(np.float32)[None, :, :, None].repeat(g["Ip"].shape[0], 0)
+    pose = dev(g["pose"]).requires_grad_(True)
+    Ic2, _, _ = G.warp_p2c(dev(smooth), coord_p, coord_c.detach(), pose)
+    Ic2.backward(dev(g["g"]))
+    pr = t(g["pose"]).requires_grad_(True)
+    cp, cc = t(coord_p.cpu().numpy()), t(coord_c.detach().cpu().numpy())
+    Ic_r, _, _ = orc.warp_p2c(t(smooth), cp, cc, pr, float(g["cx"]), float(g["cy"]))
+    Ic_r.backward(t(g["g"]))
+    assert rel_err(Ic2.detach().cpu().numpy(), Ic_r.detach().numpy()) < TOL
+    assert rel_err(pose.grad.cpu().numpy(), pr.grad.numpy()) < 2e-3     # sums of ~6000 bilinear-weight gradients each
 
 
 def test_warp_native_800x1200(mods, golden):
