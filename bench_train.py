@@ -28,9 +28,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--loss", choices=("rank_mean", "global"), default="rank_mean",
+                    help="global: masked sums and counts added over ranks before the losses are formed (the reference's "
+                         "batch semantics); rank_mean: per-rank losses, averaged gradients")
+    ap.add_argument("--buckets", type=int, default=3, help="ranges the 69 MB gradient buffer is all-reduced in")
+    ap.add_argument("--no-overlap", action="store_true", help="start the all-reduce after backward instead of from hooks")
     args = ap.parse_args()
     from fc3d import capture, dist as fdist, synth
-    import geometry_pytorch as G
     import optics_pytorch as O
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
@@ -40,14 +44,11 @@ def main():
     H = W = args.size
     sc = synth.make_scene(args.batch, H, W, fdist.shard_seed(3000, rank), pose_scale=min(1.0, W / 512))
     O.PSFs_np = synth.make_psfs(21, 5, "disc")
-    K = np.diag([1666.67, 1666.67, 1, 1])
-    K[0][2], K[1][2] = W / 2, H / 2
-    Kb = torch.from_numpy(K).float().to(dev).unsqueeze(0).repeat(args.batch, 1, 1)
-    G.get_intrinsic = lambda B, device="cuda": Kb[:B]
     d = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
     z_p, z_c, pose = d(sc["z_p"]), d(sc["z_c"]), d(sc["pose_p2c"])
     torch.manual_seed(1234)          # identical initial weights on every rank
-    step = capture.TrainStep(dev)
+    step = capture.TrainStep(dev, intrinsics=(W / 2, H / 2), loss=args.loss, n_buckets=args.buckets,
+                             overlap=not args.no_overlap)
     # The first steps can sit in the convolution library's kernel search for minutes without a
     # word; a heartbeat on stderr tells a watching harness that the run is alive.
     import threading
@@ -74,13 +75,25 @@ def main():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     el = fdist.max_over_ranks(time.perf_counter() - t0, dev)
+    # where the step goes: the capture simulation alone, timed the same way
+    with torch.no_grad():
+        capture.forward_model(z_p, z_c, pose, 21, True, None, intrinsics=(W / 2, H / 2))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            capture.forward_model(z_p, z_c, pose, 21, True, None, intrinsics=(W / 2, H / 2))
+        torch.cuda.synchronize()
+        sim_ms = 1e3 * (time.perf_counter() - t1) / args.steps
     if rank == 0:
         print(json.dumps({"metric": "training steps/sec (capture simulation + 2 U-Nets + reproj loss + Adam), data parallel",
                           "value": args.steps / el, "unit": "steps/s", "samples_per_s": world * args.batch * args.steps / el,
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
                           "scaling": "weak", "dtype": "f32", "data": "synthetic",
                           "config": {"workload": f"{args.batch}x{H}x{W} per GPU, global batch {world * args.batch}",
-                                     "grad_allreduce_bytes": step.bucket.nbytes}, "loss": float(loss)}), flush=True)
+                                     "grad_allreduce_bytes": step.bucket.nbytes, "grad_ranges": len(step.bucket.ranges),
+                                     "overlap": step.bucket.overlap, "loss_mode": args.loss},
+                          "capture_simulation_ms": sim_ms, "capture_share": sim_ms / (1e3 * el / args.steps),
+                          "loss": float(loss)}), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -9,6 +9,9 @@ Unlike the reference these functions take the image size from their inputs
 (the reference hard-codes 800x1200 and a 512 centre crop), accept the pattern
 and the noise tensors as arguments (so runs are reproducible on any device),
 and build the ray table once per size instead of with a per-pixel Python loop.
+The reference's intrinsic matrix puts the principal point at (600, 400) whatever
+the image size (geometry_pytorch.py:247-249): it is only right for 800x1200, so
+every function here takes `intrinsics` and refuses other sizes without it.
 """
 from __future__ import annotations
 
@@ -69,12 +72,19 @@ def local_norm(Im, kernelsize=17, constant=0.01):
     return Im / (mean + constant)
 
 
-def cost_rms_mask(GT, hat, mask, eps=1e-6):
-    return torch.sqrt(torch.sum(torch.square(mask * (GT - hat))) / torch.sum(mask).clamp(min=eps) + eps)
+def _same(v):
+    return v
 
 
-def cost_L1_mask(GT, hat, mask):
-    return torch.sum(mask * torch.abs(GT - hat)) / (torch.sum(mask) + 1)
+def cost_rms_mask(GT, hat, mask, eps=1e-6, reduce=_same):
+    """utils_pytorch.py:148-163.  reduce: applied to the numerator sum and to the mask count
+    (fc3d.dist.sum_over_ranks gives the loss over the global batch of a data-parallel step)."""
+    return torch.sqrt(reduce(torch.sum(torch.square(mask * (GT - hat)))) / reduce(torch.sum(mask)).clamp(min=eps) + eps)
+
+
+def cost_L1_mask(GT, hat, mask, reduce=_same):
+    """utils_pytorch.py:166-177."""
+    return reduce(torch.sum(mask * torch.abs(GT - hat))) / (reduce(torch.sum(mask)) + 1)
 
 
 def erode(mask, k):
@@ -86,11 +96,11 @@ def erode(mask, k):
     return (m > 0.999).float()
 
 
-def cost_grad_mask(GT, hat, mask):
+def cost_grad_mask(GT, hat, mask, reduce=_same):
     me = erode(mask, 9)
     GTy, GTx = image_gradients(GT)
     hy, hx = image_gradients(hat)
-    return cost_rms_mask(GTx, hx, me) + cost_rms_mask(GTy, hy, me)
+    return cost_rms_mask(GTx, hx, me, reduce=reduce) + cost_rms_mask(GTy, hy, me, reduce=reduce)
 
 
 def centre_crop(t, N):
@@ -101,12 +111,39 @@ def centre_crop(t, N):
     return t[:, h0:h0 + N, w0:w0 + N, :]
 
 
+def resolve_intrinsics(intrinsics, B, H, W, dev):
+    """[B,4,4] intrinsic matrices for images of H x W.  intrinsics: None, a (cx, cy) principal point
+    (focal length 1666.67 as in the reference), or a [4,4] / [B,4,4] tensor.  None means the
+    reference's matrix and is accepted only for 800x1200 images -- or when the caller has rebound
+    geometry_pytorch.get_intrinsic, whose result is then used as it would be by the drop-in operators."""
+    if intrinsics is None:
+        if G.get_intrinsic is not G._get_intrinsic_builtin or (H, W) == (800, 1200):
+            return G._intrinsics_for(B, dev)
+        raise ValueError(f"images of {H}x{W}: the reference's intrinsic matrix (principal point 600, 400) is for 800x1200 "
+                         "only; pass intrinsics=(cx, cy) or a 4x4 matrix")
+    if isinstance(intrinsics, torch.Tensor):
+        K = intrinsics.to(device=dev, dtype=torch.float32)
+        if K.dim() == 2:
+            K = K.unsqueeze(0)
+        if tuple(K.shape[1:]) != (4, 4) or K.shape[0] not in (1, B):
+            raise ValueError(f"intrinsics must be [4,4] or [{B},4,4], got {tuple(intrinsics.shape)}")
+        return K.expand(B, 4, 4).contiguous()
+    cx, cy = intrinsics
+    key = ("K", float(cx), float(cy), B, str(dev))
+    if key not in _consts:
+        M = np.diag([1666.67, 1666.67, 1, 1])
+        M[0][2], M[1][2] = cx, cy
+        _consts[key] = torch.from_numpy(M).float().to(dev).unsqueeze(0).repeat(B, 1, 1)
+    return _consts[key]
+
+
 def _draw_noise(B, H, W, dev):
     return dict(offset=torch.rand(B, 1, 1, 1, device=dev), gauss=torch.randn(B, H, W, 1, device=dev),
                 scale=torch.rand(B, 1, 1, 1, device=dev))
 
 
-def forward_model(z_p, z_c, pose_p2c, n_layers=21, is_conv_psf=True, crop=None, noise=None, pattern=None, fused=True):
+def forward_model(z_p, z_c, pose_p2c, n_layers=21, is_conv_psf=True, crop=None, noise=None, pattern=None, fused=True,
+                  intrinsics=None):
     """Simulated capture; train_pytorch.py:79-162.  noise: optional dict(offset [B,1,1,1] in
     [0,1), gauss [B,H,W,1] ~ N(0,1), scale [B,1,1,1] in [0,1)); drawn on the device if absent.
     fused=True (used when nothing asks for a gradient, as in the reference's loop) runs the
@@ -114,6 +151,7 @@ def forward_model(z_p, z_c, pose_p2c, n_layers=21, is_conv_psf=True, crop=None, 
     fused=False composes the drop-in operators with tensor arithmetic as the reference does."""
     B, H, W, _ = z_p.shape
     dev = z_p.device
+    K = resolve_intrinsics(intrinsics, B, H, W, dev) if B > 0 else None
     Ip = dot_pattern(H, W, dev) if pattern is None else pattern
     if noise is None:
         noise = _draw_noise(B, H, W, dev)
@@ -129,8 +167,7 @@ def forward_model(z_p, z_c, pose_p2c, n_layers=21, is_conv_psf=True, crop=None, 
             Ip_coded = ops.code_pattern_shaded(Ip0, z_p, O._layer_grid(n_layers))
         # the launch that forms the two transforms also clears the visibility mask for the splat
         mask = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
-        T_p2c, T_c2p, _ = ops.pose_transforms(pose_p2c.detach(), G._intrinsics_for(B, dev), want_fwd=True, want_inv=True,
-                                              clear=mask)
+        T_p2c, T_c2p, _ = ops.pose_transforms(pose_p2c.detach(), K, want_fwd=True, want_inv=True, clear=mask)
         Ic, xyz_cView, mask = ops.capture_warp(Ip_coded, z_p, z_c, rx, ry, T_p2c, T_c2p, zero_mask=mask)
         Ic_scaled, Ic_mask = ops.capture_post(Ic, noise["offset"], noise["gauss"], noise["scale"], mask)
         return (c(Ic_scaled), c(Ic_mask), c(xyz_cView), c(xy), c(z_c), c(z_p), pose_p2c, z_p, c(Ic), Ip_coded,
@@ -140,7 +177,7 @@ def forward_model(z_p, z_c, pose_p2c, n_layers=21, is_conv_psf=True, crop=None, 
     coord_c = G.points_in_camera_coords(z_c, rays).permute(0, 3, 1, 2)
     Ip_ref = with_reflectance(Ip, z_p)
     Ip_coded = O.codePattern(Ip_ref, z_p, is_conv_psf=is_conv_psf, n_layers=n_layers)
-    Ic, grid_p2c, grid_c2p = G.warp_p2c(Ip_coded, coord_p, coord_c, pose_p2c)
+    Ic, grid_p2c, grid_c2p = G._warp_p2c(Ip_coded, coord_p, coord_c, pose_p2c, K)
     Ic_exp = Ic + noise["offset"] * 0.05 + noise["gauss"] * 0.005
     Ic_max = Ic_exp.amax(dim=(1, 2), keepdim=True)
     Ic_scaled = torch.clamp(Ic_exp / Ic_max * (noise["scale"] * 0.3 + 0.7), 0.0, 1.0)
@@ -150,14 +187,15 @@ def forward_model(z_p, z_c, pose_p2c, n_layers=21, is_conv_psf=True, crop=None, 
     return (c(Ic_scaled), c(Ic_mask), c(xyz_cView), c(xy), c(z_c), c(z_p), pose_p2c, z_p, c(Ic), Ip_coded, Ic_scaled)
 
 
-def reproject(zp, pose_p2c, xy, IpGT, fused=True):
+def reproject(zp, pose_p2c, xy, IpGT, fused=True, intrinsics=None):
     """(zc, Ic_reProj) of the re-projection chain, train_pytorch.py:194-202: camera-view projector
     depth -> camera depth -> scene points -> projector pixel -> sampled pattern.  fused=True runs
     the chain as one kernel per direction (gradient w.r.t. zp only); fused=False composes the
-    drop-in operators as the reference does (also differentiable w.r.t. xy and IpGT)."""
+    drop-in operators as the reference does (also differentiable w.r.t. IpGT).  intrinsics: of the
+    full-size image IpGT (zp and xy may be crops of it)."""
     from . import ops
+    K = resolve_intrinsics(intrinsics, zp.shape[0], IpGT.shape[1], IpGT.shape[2], zp.device)
     if fused and not (torch.is_grad_enabled() and (xy.requires_grad or IpGT.requires_grad or pose_p2c.requires_grad)):
-        K = G._intrinsics_for(zp.shape[0], zp.device)
         _, T_c2p, pose_c2p = ops.pose_transforms(pose_p2c.detach(), K, want_inv=True, want_a=True)
         return ops.ReprojectFn.apply(zp, xy, pose_c2p, T_c2p, IpGT)
     zc = G.zp_cView_to_zc(zp, pose_p2c, xy)
@@ -165,67 +203,90 @@ def reproject(zp, pose_p2c, xy, IpGT, fused=True):
     coord_c = G.points_in_camera_coords(zc, ray, allBatch=True).permute(0, 3, 1, 2)
     # inverse(pose) once, through the library's own kernel, as a detached constant
     _, _, pose_c2p = ops.pose_transforms(pose_p2c.detach(), None, want_a=True)
-    grid_c2p = G.coord0TOgrid1(coord_c, pose_c2p)
+    grid_c2p = G._coord0TOgrid1(coord_c, pose_c2p, K)
     return zc, G.bilinear_sampler(IpGT, grid_c2p)
 
 
-def reProj_IpGT(zp_cView, pose_p2c, xy, Ic, zcGT, maskC, IpGT, fused=True):
+def reProj_IpGT(zp_cView, pose_p2c, xy, Ic, zcGT, maskC, IpGT, fused=True, intrinsics=None, reduce=None):
     """Re-projection loss; train_pytorch.py:179-211 (one crop per sample).  fused=True: erosion,
     chain, masked sums and the scalar arithmetic of the losses run in the loss kernels (gradient
-    w.r.t. zp_cView only)."""
+    w.r.t. zp_cView only).  reduce: None, or a callable applied to the masked sums and the mask
+    count before the losses are formed (fc3d.dist.sum_over_ranks: the losses of the global batch)."""
     me = erode(maskC, 5)
     grads_elsewhere = torch.is_grad_enabled() and any(
         t.requires_grad for t in (pose_p2c, xy, Ic, zcGT, maskC, IpGT))
     if fused and zp_cView.is_cuda and zp_cView.shape[0] > 0 and not grads_elsewhere:
         from . import ops
-        K = G._intrinsics_for(zp_cView.shape[0], zp_cView.device)
+        K = resolve_intrinsics(intrinsics, zp_cView.shape[0], IpGT.shape[1], IpGT.shape[2], zp_cView.device)
         _, T_c2p, pose_c2p = ops.pose_transforms(pose_p2c.detach(), K, want_inv=True, want_a=True)
-        L = ops.ReprojLossFn.apply(zp_cView, me, xy, pose_c2p, T_c2p, IpGT, Ic, zcGT)
+        L = ops.ReprojLossFn.apply(zp_cView, me, xy, pose_c2p, T_c2p, IpGT, Ic, zcGT,
+                                   None if reduce is None else (lambda s: reduce(s).detach()))
         return L[0], L[1], L[2], L[3]
     zp = zp_cView * me
-    zc, Ic_reProj = reproject(zp, pose_p2c, xy, IpGT, fused)
-    loss_zc_rms = cost_rms_mask(zcGT, zc, me)
-    loss_Ic_rms = cost_rms_mask(Ic, Ic_reProj, me)
-    loss_Ic_L1 = cost_L1_mask(Ic, Ic_reProj, me)
+    zc, Ic_reProj = reproject(zp, pose_p2c, xy, IpGT, fused, intrinsics)
+    r = _same if reduce is None else reduce
+    loss_zc_rms = cost_rms_mask(zcGT, zc, me, reduce=r)
+    loss_Ic_rms = cost_rms_mask(Ic, Ic_reProj, me, reduce=r)
+    loss_Ic_L1 = cost_L1_mask(Ic, Ic_reProj, me, reduce=r)
     return loss_Ic_L1 + loss_zc_rms, loss_zc_rms, loss_Ic_rms, loss_Ic_L1
 
 
-def cal_cost(xyz, xyz_hat, mask):
+def cal_cost(xyz, xyz_hat, mask, reduce=_same):
     """Reconstruction loss; train_pytorch.py:214-230."""
-    l_xy = cost_rms_mask(xyz[..., :2], xyz_hat[..., :2], mask)
-    l_z = cost_rms_mask(xyz[..., 2:3], xyz_hat[..., 2:3], mask)
-    l_g = cost_grad_mask(xyz[..., 2:3], xyz_hat[..., 2:3], erode(mask, 5))
+    l_xy = cost_rms_mask(xyz[..., :2], xyz_hat[..., :2], mask, reduce=reduce)
+    l_z = cost_rms_mask(xyz[..., 2:3], xyz_hat[..., 2:3], mask, reduce=reduce)
+    l_g = cost_grad_mask(xyz[..., 2:3], xyz_hat[..., 2:3], erode(mask, 5), reduce=reduce)
     return l_xy + l_z + l_g, l_xy, l_z, l_g
 
 
 class TrainStep:
-    """One optimisation step of the reference's loop (train_pytorch.py:283-304) on a
-    per-rank batch; gradients of the two U-Nets are averaged over ranks in one flat
-    all-reduce that is started right after backward."""
+    """One optimisation step of the reference's loop (train_pytorch.py:283-304) on a per-rank batch.
+    The gradients of the two U-Nets live in one flat buffer cut into three ranges; each range's
+    all-reduce (RCCL) is started from an autograd hook as soon as backward has filled it, so the
+    transfers overlap the rest of the backward pass.
 
-    def __init__(self, device, n_layers=21, is_conv_psf=True, crop=None, lr=1e-4, weight_reproj=1.0):
+    loss: "rank_mean" -- every rank forms the reference's losses on its own batch and the gradients
+    are averaged (the usual data-parallel approximation); "global" -- the masked sums and mask
+    counts are added over ranks before the losses are formed (utils_pytorch.py:161-163, :177), so
+    the step equals a single-process step on the concatenated batch up to BatchNorm statistics,
+    which stay per rank."""
+
+    def __init__(self, device, n_layers=21, is_conv_psf=True, crop=None, lr=1e-4, weight_reproj=1.0, intrinsics=None,
+                 loss="rank_mean", n_buckets=3, overlap=True):
         from . import dist as fdist
         from . import nets
+        if loss not in ("rank_mean", "global"):
+            raise ValueError(f"unknown loss mode {loss!r}")
         self.model_xy = nets.UNet_xy().to(device)
         self.model_z = nets.UNet_z().to(device)
+        self.intrinsics = intrinsics
         self.params = list(self.model_xy.parameters()) + list(self.model_z.parameters())
-        self.bucket = fdist.FlatGradBucket(self.params)
+        # every rank starts from rank 0's weights and BatchNorm statistics, whatever its own seed was
+        fdist.broadcast_module_state([self.model_xy, self.model_z])
+        self.bucket = fdist.FlatGradBucket(self.params, n_buckets=n_buckets, overlap=overlap)
         self.opt = torch.optim.Adam(self.params, lr=lr)
         self.n_layers, self.is_conv_psf, self.crop, self.w = n_layers, is_conv_psf, crop, weight_reproj
+        self.loss_mode = loss
+        self._reduce = fdist.sum_over_ranks if loss == "global" else None
+        self._world = fdist.dist.get_world_size() if (fdist.dist.is_available() and fdist.dist.is_initialized()) else 1
 
     def __call__(self, z_p, z_c, pose_p2c, noise=None):
         self.model_xy.train()
         self.model_z.train()
         with torch.no_grad():
             (Ic_s, Ic_m, xyz, xy, zc, zp, pose, _zp_full, Ic, Ip_coded, _) = forward_model(
-                z_p, z_c, pose_p2c, self.n_layers, self.is_conv_psf, self.crop, noise)
+                z_p, z_c, pose_p2c, self.n_layers, self.is_conv_psf, self.crop, noise, intrinsics=self.intrinsics)
         inp = local_norm(Ic_s, 17, 0.01)
         xyz_hat = torch.cat([self.model_xy(inp), self.model_z(inp)], dim=-1)
-        loss_recon, *_ = cal_cost(xyz, xyz_hat, Ic_m)
-        loss_reproj, *_ = reProj_IpGT(xyz_hat[..., 2:3], pose, xy, Ic, zc, Ic_m, Ip_coded)
+        red = self._reduce
+        loss_recon, *_ = cal_cost(xyz, xyz_hat, Ic_m, reduce=_same if red is None else red)
+        loss_reproj, *_ = reProj_IpGT(xyz_hat[..., 2:3], pose, xy, Ic, zc, Ic_m, Ip_coded, intrinsics=self.intrinsics,
+                                      reduce=red)
         loss = loss_recon + loss_reproj * self.w
         self.bucket.zero()
-        loss.backward()
+        # global mode: every rank holds its share of the gradient of the same loss, the shares add up;
+        # the bucket averages, hence the factor
+        (loss * self._world if red is not None else loss).backward()
         self.bucket.average(async_op=True)
         self.bucket.wait()
         self.opt.step()

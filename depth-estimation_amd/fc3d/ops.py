@@ -519,7 +519,10 @@ class ReprojLossFn(torch.autograd.Function):
     loss_Ic_L1).  zc and the re-projected pattern never reach memory; gradient w.r.t. zp_hat only."""
 
     @staticmethod
-    def forward(ctx, zp_hat, mask, xy, inv, T, img, Ic, zcGT):
+    def forward(ctx, zp_hat, mask, xy, inv, T, img, Ic, zcGT, sum_reduce=None):
+        # sum_reduce: optional callable applied to the four masked sums before the losses are formed
+        # (data-parallel training with the reference's global-sum / global-count losses: the sums
+        # are added over ranks, every rank then evaluates and differentiates the same global loss)
         dev = _need_gpu(zp_hat, mask, xy, inv, T, img, Ic, zcGT)
         B, H, W, _ = zp_hat.shape
         one = (B, H, W, 1)
@@ -540,6 +543,14 @@ class ReprojLossFn(torch.autograd.Function):
                                              im.shape[1], im.shape[2], ws.data_ptr(), sums.data_ptr(),
                                              sums.data_ptr() + 16),
                    "fc3d_reproj_loss_fwd")
+        if sum_reduce is not None:
+            S = sum_reduce(sums[0:4].clone())
+            sums[0:4] = S
+            # the reference's fp32 expressions (utils_pytorch.py:161-163, :177; train_pytorch.py:209)
+            nc = S[3].clamp(min=1e-6)
+            zc_rms, ic_rms = torch.sqrt(S[0] / nc + 1e-6), torch.sqrt(S[1] / nc + 1e-6)
+            l1 = S[2] / (S[3] + 1)
+            sums[4:8] = torch.stack([l1 + zc_rms, zc_rms, ic_rms, l1])
         ctx.save_for_backward(sums, *ts)
         return sums[4:8].clone()
 
@@ -556,7 +567,7 @@ class ReprojLossFn(torch.autograd.Function):
                                              a.data_ptr(), t.data_ptr(), im.data_ptr(), ic.data_ptr(), zg.data_ptr(),
                                              B, H, W, im.shape[1], im.shape[2], gz.data_ptr()),
                    "fc3d_reproj_loss_bwd")
-        return gz, None, None, None, None, None, None, None
+        return gz, None, None, None, None, None, None, None, None
 
 
 # --------------------------------------------------------------------------- #

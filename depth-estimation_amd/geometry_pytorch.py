@@ -137,9 +137,15 @@ def coord_transform(coord, transform):
 
 def coord0TOgrid1(coord0, pose01):
     """Scene points of view 0 -> pixel coordinates in view 1 (geometry_pytorch.py:93-106)."""
+    return _coord0TOgrid1(coord0, pose01, None)
+
+
+def _coord0TOgrid1(coord0, pose01, K):
+    """coord0TOgrid1 with the intrinsic matrix as an argument (None: get_intrinsic's)."""
     if coord0.shape[0] == 0:
         return coord0.new_zeros((0, coord0.shape[2], coord0.shape[3], 2))
-    K = _intrinsics_for(coord0.shape[0], coord0.device)
+    if K is None:
+        K = _intrinsics_for(coord0.shape[0], coord0.device)
     if pose01.requires_grad and torch.is_grad_enabled():
         T, _, _ = _ops.PoseTransformsFn.apply(pose01, K)       # K @ pose with the gradient K^T g
     else:
@@ -178,12 +184,18 @@ def z2pointcloud(z):
 def warp_p2c(Ip, coord_p, coord_c, pose_p2c):
     """Projector image -> camera view with occluded pixels blacked out
     (geometry_pytorch.py:255-281).  Returns (Ic_masked, grid_p2c, grid_c2p)."""
+    return _warp_p2c(Ip, coord_p, coord_c, pose_p2c, None)
+
+
+def _warp_p2c(Ip, coord_p, coord_c, pose_p2c, K):
+    """warp_p2c with the intrinsic matrix as an argument (None: get_intrinsic's)."""
     if Ip.shape[0] == 0:                          # empty batch
         e = coord_p.new_zeros((0, coord_p.shape[2], coord_p.shape[3], 2))
         return Ip.clone(), e, e.clone()
     if torch.is_grad_enabled() and (coord_p.requires_grad or coord_c.requires_grad or pose_p2c.requires_grad):
         # rare differentiable-geometry case: compose the individual operators
-        K = _intrinsics_for(coord_p.shape[0], coord_p.device)
+        if K is None:
+            K = _intrinsics_for(coord_p.shape[0], coord_p.device)
         if pose_p2c.requires_grad:
             T_p2c, T_c2p, _ = _ops.PoseTransformsFn.apply(pose_p2c, K)
         else:
@@ -192,7 +204,8 @@ def warp_p2c(Ip, coord_p, coord_c, pose_p2c):
         Ic = _ops.BilinearFn.apply(Ip, grid_c2p)
         grid_p2c = _ops.ProjectFn.apply(coord_p, T_p2c)
         return Ic * _ops.visible_mask(grid_p2c, 0), grid_p2c, grid_c2p
-    K = _intrinsics_for(coord_p.shape[0], coord_p.device)
+    if K is None:
+        K = _intrinsics_for(coord_p.shape[0], coord_p.device)
     # the launch that forms the two transforms also clears the visibility mask for the splat
     B, _, H, W = coord_p.shape
     mask = torch.empty((B, H, W), dtype=torch.uint8, device=coord_p.device)

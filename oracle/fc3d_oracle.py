@@ -280,3 +280,76 @@ def reproject_chain(zp_cView, pose_p2c, xy, IpGT, cx, cy, pose_c2p=None):
     coord_c = points_in_camera_coords(zc, ray, allBatch=True).permute(0, 3, 1, 2)
     grid_c2p = coord0TOgrid1(coord_c, pose_c2p, cx, cy)
     return zc, grid_c2p, bilinear_sampler(IpGT, grid_c2p)
+
+
+# --------------------------------------------------------------------------- #
+# the two callers as the training script composes them (pinned by g9_callers.npz, which holds what
+# the reference's own forward_model / reProj_IpGT returned at 800x1200)
+# --------------------------------------------------------------------------- #
+def image_gradients(img):
+    """Forward differences, zero in the last row / column; utils_pytorch.py:206-222."""
+    dy = F.pad(img[:, 1:] - img[:, :-1], (0, 0, 0, 0, 0, 1))
+    dx = F.pad(img[:, :, 1:] - img[:, :, :-1], (0, 0, 0, 1, 0, 0))
+    return dy, dx
+
+
+def withReflectance(I, depth):
+    """I * (0.8 cos(atan(|grad z| / 100 um)) + 0.2); utils_pytorch.py:251-280."""
+    dy, dx = image_gradients(depth)
+    theta = torch.atan(torch.sqrt(dy ** 2 + dx ** 2) / 100e-6)
+    return I * (torch.cos(theta) * 0.8 + 0.2)
+
+
+def cost_rms_mask(GT, hat, mask, eps=1e-6):
+    """utils_pytorch.py:148-163."""
+    return torch.sqrt(torch.sum(torch.square(mask * (GT - hat))) / torch.sum(mask).clamp(min=eps) + eps)
+
+
+def cost_L1_mask(GT, hat, mask):
+    """utils_pytorch.py:166-177."""
+    return torch.sum(mask * torch.abs(GT - hat)) / (torch.sum(mask) + 1)
+
+
+def erode(mask, k):
+    """1 where the whole k x k neighbourhood is 1; train_pytorch.py:184-186, :222-224."""
+    m = F.avg_pool2d(mask.permute(0, 3, 1, 2), kernel_size=k, stride=1, padding=k // 2).permute(0, 2, 3, 1)
+    return (m > 0.999).float()
+
+
+def centre_crop(t, N):
+    """multi_rand_crop with the centre offset forward_model passes; train_pytorch.py:56-73, :142-152."""
+    H, W = t.shape[1:3]
+    h0, w0 = (H - N) // 2, (W - N) // 2
+    return t[:, h0:h0 + N, w0:w0 + N, :]
+
+
+def forward_model(z_p, z_c, pose_p2c, pattern, psfs, noise, is_conv_psf=True, crop=512, cx=600.0, cy=400.0,
+                  pose_c2p=None):
+    """The simulated capture, train_pytorch.py:79-162, with the pattern (gen_pattern's result, :90) and
+    the three random draws (:100, :102: offset [B,1,1,1] and scale [B,1,1,1] uniform in [0,1), gauss
+    [B,H,W,1] standard normal) passed in.  Returns the reference's eleven outputs in its order."""
+    B, H, W, _ = z_p.shape
+    coord_p = z2pointcloud(z_p)                                               # :86-87
+    coord_c = z2pointcloud(z_c)
+    Ip_ref = withReflectance(pattern, z_p)                                    # :91
+    Ip_coded = codePattern(Ip_ref, z_p, psfs, is_conv_psf)                    # :94
+    Ic, grid_p2c, grid_c2p = warp_p2c(Ip_coded, coord_p, coord_c, pose_p2c, cx, cy, pose_c2p)   # :97
+    Ic_exp = Ic + noise["offset"] * 0.05 + noise["gauss"] * 0.005             # :100
+    Ic_max = torch.max(torch.max(Ic_exp, dim=1, keepdim=True)[0], dim=2, keepdim=True)[0]       # :101
+    Ic_scaled = torch.clamp(Ic_exp / Ic_max * (noise["scale"] * 0.3 + 0.7), 0.0, 1.0)           # :102-104
+    vis = gen_visible_mask(grid_p2c, 'all')                                   # :107
+    xy = torch.from_numpy(pixel_to_ray_array(W, H)[:, :, 0:2]).float().unsqueeze(0).repeat(B, 1, 1, 1)   # :110-112
+    xyz_cView = bilinear_sampler(torch.cat([xy, z_p], dim=-1), grid_c2p) * vis                  # :115-116
+    Ic_mask = (Ic_scaled > 0.05).float() * vis                                # :118
+    c = (lambda t: centre_crop(t, crop)) if crop else (lambda t: t)           # :138-160
+    return (c(Ic_scaled), c(Ic_mask), c(xyz_cView), c(xy), c(z_c), c(z_p), pose_p2c, z_p, c(Ic), Ip_coded, Ic_scaled)
+
+
+def reProj_IpGT(zp_cView, pose_p2c, xy, Ic, zcGT, maskC, IpGT, cx=600.0, cy=400.0, pose_c2p=None):
+    """The re-projection loss, train_pytorch.py:179-211 (one crop per sample, B_sub = 1)."""
+    me = erode(maskC, 5)                                                      # :184-186
+    zc, _, Ic_reProj = reproject_chain(zp_cView * me, pose_p2c, xy, IpGT, cx, cy, pose_c2p)     # :188-202
+    loss_zc_rms = cost_rms_mask(zcGT, zc, me)                                 # :205-207
+    loss_Ic_rms = cost_rms_mask(Ic, Ic_reProj, me)
+    loss_Ic_L1 = cost_L1_mask(Ic, Ic_reProj, me)
+    return loss_Ic_L1 + loss_zc_rms, loss_zc_rms, loss_Ic_rms, loss_Ic_L1     # :209-211

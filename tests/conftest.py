@@ -38,3 +38,14 @@ def rel_err(a, b):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     return float(np.max(np.abs(a - b)) / max(float(np.max(np.abs(b))), 1e-30))
+
+
+def rel_err_elem(a, b, floor=1e-3):
+    """max over the elements with |b| > floor * max|b| of |a-b| / |b|: a per-element relative error
+    that ignores values too small to carry one (next to rel_err, which is relative to the tensor's scale)."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    big = np.abs(b) > floor * max(float(np.max(np.abs(b))), 1e-30)
+    if not big.any():
+        return 0.0
+    return float(np.max(np.abs(a - b)[big] / np.abs(b)[big]))

@@ -347,6 +347,102 @@ def g8_utils(U):
          z=z, I=I, refl=refl, dy=dy, dx=dx, Im=Im, ln17=ln17, ln5=ln5, mask=mask, erode5=erode5, GT=GT, hat=hat0, **out)
 
 
+def g9_callers(ref_dir):
+    """The two callers of the path as the reference's training script composes them: forward_model
+    (train_pytorch.py:79-162) at its native 800x1200 and reProj_IpGT (:179-211) on its outputs.
+
+    What had to be done to run them here, recorded in the fixture's `how` entry:
+      * train_pytorch.py imports torch.utils.tensorboard.SummaryWriter (:21) for its logging loop;
+        the tensorboard package is not installed, so a module object with a SummaryWriter
+        placeholder is put into sys.modules first.  Neither function touches it.
+      * forward_model calls gen_pattern and codePattern with their default device 'cuda' (:90, :94);
+        the two names are rebound inside the imported module to functools.partial(..., device='cpu').
+      * the global PSF stack of optics_pytorch is set to fc3d.synth.make_psfs(21, 5, 'disc').
+    The reference file itself is imported unmodified.  The random draws of forward_model (:100-102)
+    come from torch's CPU generator after torch.manual_seed(seed); the test repeats the three draws.
+    Floats are stored on a stride-4 lattice of the crop (stride 8 for full-size tensors) plus float64
+    sums of every tensor; masks are stored whole, bit-packed."""
+    import functools
+    import types
+    stub = types.ModuleType("torch.utils.tensorboard")
+    stub.SummaryWriter = type("SummaryWriter", (), {"__init__": lambda self, *a, **k: None})
+    sys.modules["torch.utils.tensorboard"] = stub
+    import train_pytorch as TP
+    assert TP.__file__.startswith(ref_dir)
+    import optics_pytorch as O
+    TP.gen_pattern = functools.partial(TP.gen_pattern, device='cpu')
+    TP.codePattern = functools.partial(TP.codePattern, device='cpu')
+    how = ("sys.modules['torch.utils.tensorboard'] = placeholder module with an empty SummaryWriter class (package not "
+           "installed; unused by forward_model / reProj_IpGT); train_pytorch.gen_pattern and train_pytorch.codePattern "
+           "rebound to functools.partial(original, device='cpu'); optics_pytorch.PSFs_np = fc3d.synth.make_psfs(21, 5, 'disc'); "
+           "reference sources unmodified")
+    scene_seed, noise_seed, zhat_seed = 61, 62, 63
+    sc = synth.make_scene(1, 800, 1200, scene_seed, pose_scale=1.0)
+    z_p, z_c, pose = t(sc["z_p"]), t(sc["z_c"]), t(sc["pose_p2c"])
+    O.PSFs_np = synth.make_psfs(21, 5, "disc")
+    blob = dict(how=np.array(how), pose_c2p=torch.linalg.inv(pose), scene_seed=np.array(scene_seed), noise_seed=np.array(noise_seed),
+                zhat_seed=np.array(zhat_seed), psf_spec=np.array("make_psfs(21, 5, 'disc')"))
+    names = ["Ic_scaled_crop", "Ic_mask_crop", "xyz_cView_crop", "xy_crop", "z_c_crop", "z_p_crop", "pose", "z_p", "Ic_crop",
+             "Ip_coded", "Ic_scaled"]
+    for conv in (True, False):
+        tag = "conv" if conv else "noconv"
+        # every torch.rand / torch.randn call of the run is recorded, so that the fixture can say exactly
+        # which draws the capture consumed and the test can repeat them
+        drawn = []
+        real_rand, real_randn = torch.rand, torch.randn
+
+        def rec(fn, kind):
+            def wrapped(*a, **k):
+                v = fn(*a, **k)
+                drawn.append((kind, tuple(v.shape), v.clone()))
+                return v
+            return wrapped
+        torch.manual_seed(noise_seed)
+        torch.rand, torch.randn = rec(real_rand, "rand"), rec(real_randn, "randn")
+        try:
+            with torch.no_grad():
+                out = TP.forward_model(z_p, z_c, pose, is_train=False, is_crop=True, is_conv_psf=conv)
+        finally:
+            torch.rand, torch.randn = real_rand, real_randn
+        o = dict(zip(names, out))
+        # gen_pattern draws one value per sample first (a dot-intensity jitter that is multiplied by a
+        # sigma of 0, utils_pytorch.py:25), then forward_model draws offset, gauss, scale (:100, :102)
+        assert [(k, sh) for k, sh, _ in drawn] == [("randn", (1, 1, 1, 1)), ("rand", (1, 1, 1, 1)), ("randn", (1, 800, 1200, 1)),
+                                                   ("rand", (1, 1, 1, 1))], [(k, sh) for k, sh, _ in drawn]
+        torch.manual_seed(noise_seed)
+        torch.randn(1, 1, 1, 1)
+        off, gau, sca = torch.rand(1, 1, 1, 1), torch.randn(1, 800, 1200, 1), torch.rand(1, 1, 1, 1)
+        assert torch.equal(off, drawn[1][2]) and torch.equal(gau, drawn[2][2]) and torch.equal(sca, drawn[3][2])
+        blob["draws"] = np.array("torch.manual_seed(noise_seed); randn(1,1,1,1) [discarded]; offset = rand(1,1,1,1); "
+                                 "gauss = randn(1,800,1200,1); scale = rand(1,1,1,1)")
+        blob.update({f"{tag}_noise_offset": off, f"{tag}_noise_scale": sca,
+                     f"{tag}_noise_gauss_sum": np.array(float(gau.double().sum())),
+                     f"{tag}_noise_gauss_head": gau.reshape(-1)[:16]})
+        for k in ("Ic_scaled_crop", "xyz_cView_crop", "Ic_crop"):
+            blob[f"{tag}_{k}_s4"] = o[k][:, ::4, ::4]
+            blob[f"{tag}_{k}_sum"] = np.array(float(o[k].double().sum()))
+        blob[f"{tag}_Ic_scaled_s8"] = o["Ic_scaled"][:, ::8, ::8]
+        blob[f"{tag}_Ic_scaled_sum"] = np.array(float(o["Ic_scaled"].double().sum()))
+        # the coded pattern is a dot array (zero on most of any lattice): a dense patch instead
+        blob[f"{tag}_Ip_coded_patch"] = o["Ip_coded"][:, 300:460, 500:660]
+        blob[f"{tag}_Ip_coded_sum"] = np.array(float(o["Ip_coded"].double().sum()))
+        blob[f"{tag}_Ic_mask_crop_bits"] = np.packbits(o["Ic_mask_crop"].numpy().astype(np.uint8).reshape(-1))
+        assert torch.equal(o["z_p"], z_p) and torch.equal(o["pose"], pose)
+        h0, w0 = (800 - 512) // 2, (1200 - 512) // 2
+        assert torch.equal(o["z_c_crop"], z_c[:, h0:h0 + 512, w0:w0 + 512]) and torch.equal(o["z_p_crop"], z_p[:, h0:h0 + 512, w0:w0 + 512])
+        blob[f"{tag}_xy_crop_corners"] = o["xy_crop"][0, [0, 0, -1, -1], [0, -1, 0, -1]]
+        # the re-projection loss on these outputs for a noisy prediction of the projector-frame depth
+        torch.manual_seed(zhat_seed)
+        zhat = (o["xyz_cView_crop"][..., 2:3] + 0.003 * torch.randn(1, 512, 512, 1)).requires_grad_(True)
+        losses = TP.reProj_IpGT(zhat, o["pose"], o["xy_crop"], o["Ic_crop"], o["z_c_crop"], o["Ic_mask_crop"], o["Ip_coded"])
+        losses[0].backward()
+        blob[f"{tag}_reproj_losses"] = np.array([float(v) for v in losses], np.float32)
+        blob[f"{tag}_reproj_grad_s4"] = zhat.grad[:, ::4, ::4]
+        blob[f"{tag}_reproj_grad_sum"] = np.array(float(zhat.grad.double().sum()))
+        blob[f"{tag}_reproj_grad_abs_sum"] = np.array(float(zhat.grad.double().abs().sum()))
+    save("g9_callers", **blob)
+
+
 def g0_rays(G):
     """pixel_to_ray_array / pixel_to_ray / get_intrinsic / z2pointcloud constants."""
     r = G.pixel_to_ray_array(width=24, height=10)
@@ -358,6 +454,7 @@ def g0_rays(G):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--only", default=None, help="regenerate one fixture only (e.g. g9)")
     args = ap.parse_args()
     sys.path.insert(0, args.ref)
     os.chdir(HERE)                      # no psfs_exp.npy here -> reference uses its dummy stack
@@ -365,6 +462,9 @@ def main():
     import optics_pytorch as O
     import geometry_pytorch as G
     assert O.__file__.startswith(args.ref) and G.__file__.startswith(args.ref)
+    if args.only == "g9":
+        g9_callers(args.ref)
+        return
     g0_rays(G)
     g1_layers(O)
     g2_code_pattern(O)
@@ -376,6 +476,7 @@ def main():
     import utils_pytorch as U
     assert U.__file__.startswith(args.ref)
     g8_utils(U)
+    g9_callers(args.ref)
 
 
 if __name__ == "__main__":

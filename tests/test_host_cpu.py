@@ -194,6 +194,50 @@ assert torch.allclose(bucket.flat, sum(allg) / world, atol=1e-7)
 assert all(p.grad.data_ptr() >= bucket.flat.data_ptr() for p in net.parameters())   # still views of the bucket
 assert fdist.max_over_ranks(float(rank + 1)) == 2.0
 assert fdist.shard_seed(1000, rank) == 1000 + 100 * rank
+
+# --- replicas start from rank 0's weights whatever their own seed was
+torch.manual_seed(100 + rank)
+conv = lambda: torch.nn.Sequential(torch.nn.Conv2d(1, 4, 3, padding=1), torch.nn.Tanh(), torch.nn.Conv2d(4, 4, 3, padding=1),
+                                   torch.nn.Tanh(), torch.nn.Conv2d(4, 1, 3, padding=1))
+net = conv()
+fdist.broadcast_module_state([net])
+w0 = [p.detach().clone() for p in net.parameters()]
+g0 = [torch.zeros_like(w) for w in w0]
+for w, g in zip(w0, g0):
+    g.copy_(w); torch.distributed.broadcast(g, 0); assert torch.equal(g, w)
+
+# --- three ranges, all-reduces started from autograd hooks while backward is still running:
+#     the averaged gradient of per-rank mean losses == the gradient of the mean loss over the
+#     concatenated batch in one process
+gen = torch.Generator().manual_seed(7)
+X = torch.rand(4, 1, 8, 8, generator=gen); Y = torch.rand(4, 1, 8, 8, generator=gen); M = (torch.rand(4, 1, 8, 8, generator=gen) > 0.3).float()
+single = conv(); single.load_state_dict(net.state_dict())
+(single(X) - Y).square().mean().backward()
+bucket = fdist.FlatGradBucket(net.parameters(), n_buckets=3, overlap=True)
+assert len(bucket.ranges) == 3 and bucket.ranges[0][0] == 0 and bucket.ranges[-1][1] == bucket.flat.numel()
+sl = slice(2 * rank, 2 * rank + 2)
+for _ in range(2):                     # twice: the per-range counters re-arm
+    bucket.zero()
+    (net(X[sl]) - Y[sl]).square().mean().backward()
+    assert len(bucket._handles) == 3   # every range went out during backward
+    bucket.average(async_op=True); bucket.wait()
+    for p, q in zip(net.parameters(), single.parameters()):
+        assert torch.allclose(p.grad, q.grad, atol=1e-7), (p.grad - q.grad).abs().max()
+
+# --- the reference's masked losses are global sums over global counts (utils_pytorch.py:161-163):
+#     with the sums added over ranks every rank sees the single-process loss, and the SUM of the
+#     ranks' gradients is its gradient
+def masked_rms(gt, hat, m, reduce):
+    return torch.sqrt(reduce(torch.sum(torch.square(m * (gt - hat)))) / reduce(torch.sum(m)).clamp(min=1e-6) + 1e-6)
+single.zero_grad()
+Ls = masked_rms(Y, single(X), M, lambda v: v); Ls.backward()
+bucket = fdist.FlatGradBucket(net.parameters(), n_buckets=2, overlap=True, average=False)
+bucket.zero()
+Lg = masked_rms(Y[sl], net(X[sl]), M[sl], fdist.sum_over_ranks); Lg.backward()
+bucket.average(); 
+assert abs(float(Lg) - float(Ls)) < 1e-6
+for p, q in zip(net.parameters(), single.parameters()):
+    assert torch.allclose(p.grad, q.grad, atol=1e-6), (p.grad - q.grad).abs().max()
 torch.distributed.barrier()
 torch.distributed.destroy_process_group()
 print("rank", rank, "ok")
@@ -212,8 +256,10 @@ def test_data_parallel_helpers_gloo_two_ranks(tmp_path):
 
 
 def test_capture_data_shards(tmp_path):
-    """The .npz reader: uint16 depth decoding (value/50000 + 0.3), split discovery, per-rank shares
-    that are disjoint, equally long and cover whole batches only, seeded shuffling."""
+    """The .npz reader: stored values passed through as float32 like the reference's loader
+    (data_provider_pytorch.py:32-36), optional decoding of raw uint16 codes (value/50000 + 0.3), split
+    discovery, per-rank shares that are disjoint, equally long and cover whole batches only, seeded
+    shuffling, memory-mapped and compressed archives."""
     from fc3d import data, synth
     sc = synth.make_scene(11, 16, 24, 5)
     root = str(tmp_path) + os.sep
@@ -223,16 +269,25 @@ def test_capture_data_shards(tmp_path):
         data.read_data(root, 2, "valid")
     codes = np.load(root + "train_a.npz")["z_p"]
     assert codes.dtype == np.uint16
-    assert np.array_equal(data.decode_depth(codes), codes.astype(np.float32) / np.float32(50000) + np.float32(0.3))
-    assert np.abs(data.decode_depth(codes) - sc["z_p"]).max() <= 0.5 / 50000 + 1e-7
+    assert np.array_equal(data.decode_depth(codes, True), codes.astype(np.float32) / np.float32(50000) + np.float32(0.3))
+    assert np.abs(data.decode_depth(codes, True) - sc["z_p"]).max() <= 0.5 / 50000 + 1e-7
+    # default: the stored values themselves, as float32 -- what the reference's __getitem__ returns
+    raw = next(iter(data.read_data(root, 2, "train", seed=3)))
+    assert raw["z_p"].dtype == torch.float32 and float(raw["z_p"].min()) > 1000
+    assert np.array_equal(data.decode_depth(codes), codes.astype(np.float32))
+    assert isinstance(data.open_member(root + "train_a.npz", "z_p"), np.memmap)         # np.savez stores uncompressed
+    np.savez_compressed(root + "test_c.npz", z_p=sc["z_p"], z_c=sc["z_c"], pose_p2c=sc["pose_p2c"])
+    assert not isinstance(data.open_member(root + "test_c.npz", "z_p"), np.memmap)
+    assert np.array_equal(data.open_member(root + "test_c.npz", "z_c"), sc["z_c"])
     seen = []
     for rank in range(2):
-        sh = data.read_data(root, 2, "train", rank=rank, world=2, seed=3)
+        sh = data.read_data(root, 2, "train", rank=rank, world=2, seed=3, decode_uint16=True)
+        assert float(next(iter(data.read_data(root, 2, "train", rank=rank, world=2, decode_uint16=True)))["z_p"].max()) < 1.0
         assert len(sh) == 2 and len(sh.index) == 4            # 11 samples -> 5 per rank -> 2 whole batches of 2
         batches = list(sh)
         assert len(batches) == 2 and tuple(batches[0]["z_p"].shape) == (2, 16, 24, 1)
         assert batches[0]["z_p"].dtype == torch.float32 and tuple(batches[0]["pose_p2c"].shape) == (2, 4, 4)
-        again = [b["pose_p2c"] for b in data.read_data(root, 2, "train", rank=rank, world=2, seed=3)]
+        again = [b["pose_p2c"] for b in data.read_data(root, 2, "train", rank=rank, world=2, seed=3, decode_uint16=True)]
         assert all(torch.equal(a, b["pose_p2c"]) for a, b in zip(again, batches))   # same seed, same order
         seen.append(set(sh.index.tolist()))
     assert not (seen[0] & seen[1]) and all(i % 2 == r for r in range(2) for i in seen[r])

@@ -179,3 +179,52 @@ def test_reproj_chain(golden):
     assert np.array_equal(grid.detach().numpy(), g["grid"])
     assert np.array_equal(Ic.detach().numpy(), g["Ic"])
     assert rel_err(zp.grad.numpy(), g["grad_zp"]) < TIGHT
+
+
+def _g9_inputs(g):
+    """Scene, pattern, PSFs and the three random draws of the g9 fixture, rebuilt from its seeds."""
+    from fc3d import synth
+    sc = synth.make_scene(1, 800, 1200, int(g["scene_seed"]), pose_scale=1.0)
+    psfs = synth.make_psfs(21, 5, "disc")
+    pattern = torch.from_numpy(synth.dot_pattern(800, 1200)).view(1, 800, 1200, 1)
+    torch.manual_seed(int(g["noise_seed"]))
+    torch.randn(1, 1, 1, 1)            # gen_pattern's unused dot-intensity draw comes first (utils_pytorch.py:25)
+    noise = dict(offset=torch.rand(1, 1, 1, 1), gauss=torch.randn(1, 800, 1200, 1), scale=torch.rand(1, 1, 1, 1))
+    return sc, psfs, pattern, noise
+
+
+def check_g9_noise(g, tag, noise):
+    # the regenerated draws are the ones the reference consumed
+    assert np.array_equal(noise["offset"].numpy(), g[f"{tag}_noise_offset"])
+    assert np.array_equal(noise["scale"].numpy(), g[f"{tag}_noise_scale"])
+    assert np.array_equal(noise["gauss"].reshape(-1)[:16].numpy(), g[f"{tag}_noise_gauss_head"])
+    assert float(noise["gauss"].double().sum()) == float(g[f"{tag}_noise_gauss_sum"])
+
+
+@pytest.mark.parametrize("tag", ["conv", "noconv"])
+def test_callers_match_reference_outputs(golden, tag):
+    """The oracle's forward_model / reProj_IpGT against what the reference's own functions returned
+    at 800x1200 (train_pytorch.py:79-162, :179-211), bit for bit on the stored lattice."""
+    g = golden("g9_callers")
+    sc, psfs, pattern, noise = _g9_inputs(g)
+    check_g9_noise(g, tag, noise)
+    out = orc.forward_model(t(sc["z_p"]), t(sc["z_c"]), t(sc["pose_p2c"]), pattern.expand(-1, -1, -1, 21), psfs, noise,
+                            is_conv_psf=(tag == "conv"), pose_c2p=t(g["pose_c2p"]))
+    Ic_s, Ic_m, xyz, xy, zc, zp, pose, _, Ic, Ip_coded, Ic_s_full = out
+    assert np.array_equal(Ic_s[:, ::4, ::4].numpy(), g[f"{tag}_Ic_scaled_crop_s4"])
+    assert np.array_equal(xyz[:, ::4, ::4].numpy(), g[f"{tag}_xyz_cView_crop_s4"])
+    assert np.array_equal(Ic[:, ::4, ::4].numpy(), g[f"{tag}_Ic_crop_s4"])
+    assert np.array_equal(Ip_coded[:, 300:460, 500:660].numpy(), g[f"{tag}_Ip_coded_patch"])
+    assert float(np.abs(g[f"{tag}_Ip_coded_patch"]).max()) > 0.1
+    assert np.array_equal(Ic_s_full[:, ::8, ::8].numpy(), g[f"{tag}_Ic_scaled_s8"])
+    assert np.array_equal(np.packbits(Ic_m.numpy().astype(np.uint8).reshape(-1)), g[f"{tag}_Ic_mask_crop_bits"])
+    for k, v in (("Ic_scaled_crop", Ic_s), ("xyz_cView_crop", xyz), ("Ic_crop", Ic), ("Ip_coded", Ip_coded), ("Ic_scaled", Ic_s_full)):
+        assert abs(float(v.double().sum()) - float(g[f"{tag}_{k}_sum"])) <= 1e-9 * abs(float(g[f"{tag}_{k}_sum"])), k
+    assert np.array_equal(xy[0, [0, 0, -1, -1], [0, -1, 0, -1]].numpy(), g[f"{tag}_xy_crop_corners"])
+    torch.manual_seed(int(g["zhat_seed"]))
+    zhat = (xyz[..., 2:3] + 0.003 * torch.randn(1, 512, 512, 1)).requires_grad_(True)
+    losses = orc.reProj_IpGT(zhat, pose, xy, Ic, zc, Ic_m, Ip_coded, pose_c2p=t(g["pose_c2p"]))
+    losses[0].backward()
+    assert np.array_equal(np.array([float(v) for v in losses], np.float32), g[f"{tag}_reproj_losses"])
+    assert rel_err(zhat.grad[:, ::4, ::4].numpy(), g[f"{tag}_reproj_grad_s4"]) < TIGHT
+    assert abs(float(zhat.grad.double().sum()) - float(g[f"{tag}_reproj_grad_sum"])) <= 1e-6 * float(g[f"{tag}_reproj_grad_abs_sum"])
