@@ -17,6 +17,11 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "depth-estimation_amd"))
 
+# A fresh machine has no tuned-convolution database: the default search compiles and times every
+# candidate kernel of every U-Net layer shape, minutes before the first step returns.  FAST takes
+# the library's heuristic pick instead (MIOPEN_FIND_MODE=NORMAL in the environment restores the search).
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
@@ -91,7 +96,8 @@ def main():
                           "scaling": "weak", "dtype": "f32", "data": "synthetic",
                           "config": {"workload": f"{args.batch}x{H}x{W} per GPU, global batch {world * args.batch}",
                                      "grad_allreduce_bytes": step.bucket.nbytes, "grad_ranges": len(step.bucket.ranges),
-                                     "overlap": step.bucket.overlap, "loss_mode": args.loss},
+                                     "overlap": step.bucket.overlap, "loss_mode": args.loss,
+                                     "conv_find_mode": os.environ["MIOPEN_FIND_MODE"]},
                           "capture_simulation_ms": sim_ms, "capture_share": sim_ms / (1e3 * el / args.steps),
                           "loss": float(loss)}), flush=True)
     if world > 1:

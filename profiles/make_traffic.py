@@ -32,8 +32,9 @@ NAMES = (
     ("code_pattern_bwd_wide_kernel", "code_pattern_bwd"), ("code_pattern_bwd_kernel", "code_pattern_bwd"),
     ("pose_transforms_kernel", "pose_transforms"), ("project_kernel", "warp_project_splat"),
     ("warp_sample_kernel", "warp_sample"), ("bilinear_bwd_img_scatter_kernel", "bilinear_bwd_img_scatter"),
-    ("bilinear_bwd_img_merge_kernel", "bilinear_bwd_img_merge"),
-    ("bilinear_bwd_img_overflow_kernel", "bilinear_bwd_img_overflow"), ("points_fwd_kernel", "points_fwd"),
+    ("bilinear_bwd_img_gather_kernel", "bilinear_bwd_img_gather"), ("bilinear_tap_index_kernel", "bilinear_tap_index"),
+    ("project_bwd_transform_sum_kernel", "project_bwd_transform_sum"), ("project_bwd_transform_kernel", "project_bwd_transform"),
+    ("points_fwd_kernel", "points_fwd"),
     ("code_pattern_fwd_sweep_kernel", "code_pattern_fwd"), ("code_pattern_bwd_sweep_kernel", "code_pattern_bwd"),
     ("code_pattern_flat_fwd_kernel", "code_pattern_fwd"), ("code_pattern_flat_bwd_kernel", "code_pattern_bwd"),
     ("zero_fill_kernel", "zero_fill"), ("reflectance_kernel", "reflectance"),
