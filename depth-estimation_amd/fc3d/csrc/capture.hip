@@ -429,6 +429,7 @@ extern "C" int fc3d_capture_warp_fwd(void* stream, const float* Ip, const float*
     if (!Ip || !z_p || !z_c || !ray_x || !ray_y || !T_p2c || !T_c2p || !Ic_masked || !xyz_cview || !mask_u8)
         return FC3D_EINVAL;
     if (int e = check_img(B, H, W)) return e;
+    if ((long)H * W >= (1L << 29)) return FC3D_ERANGE;   // per-image byte offsets of the taps are 32-bit
     if ((reinterpret_cast<uintptr_t>(grid_p2c) & 7u) || (reinterpret_cast<uintptr_t>(grid_c2p) & 7u)) return FC3D_EALIGN;
     hipStream_t s = (hipStream_t)stream;
     dim3 g(cdiv((long)H * W, PX_PER_BLOCK), B), gp(cdiv((long)H * W, NT * CPX), B), blk(NT);

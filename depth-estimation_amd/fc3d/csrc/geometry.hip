@@ -1416,6 +1416,7 @@ extern "C" int fc3d_warp_p2c_fwd(void* stream, const float* Ip, const float* coo
     if (!Ip || !coord_p || !coord_c || !T_p2c || !T_c2p || !Ic_masked || !grid_p2c || !grid_c2p || !mask_u8)
         return FC3D_EINVAL;
     if (int e = check_img(B, H, W)) return e;
+    if ((long)H * W >= (1L << 29)) return FC3D_ERANGE;   // per-image byte offsets of the taps are 32-bit
     if (tap_index && (!gather_fits(H, W, H, W) || (reinterpret_cast<uintptr_t>(tap_index) & 7u))) return FC3D_ERANGE;
     if (!aligned4(coord_p) || !aligned4(coord_c) || !aligned4(Ip) || !aligned4(Ic_masked) ||
         (reinterpret_cast<uintptr_t>(grid_p2c) & 7u) || (reinterpret_cast<uintptr_t>(grid_c2p) & 7u))

@@ -932,9 +932,11 @@ struct Sweep {
     static constexpr int TR = NG * R;             // output rows per wavefront
     static constexpr int NR = TR + K - 1;         // staged rows
     static constexpr int LW0 = CW + K - 1;        // staged columns
-    // row stride: R * LW = 16 (mod 64) puts the NG groups' 16-lane reads into different banks
-    static constexpr int LW = NG == 1 ? LW0 : LW0 + ((4 - LW0 % 16) + 16) % 16;
+    // row stride: R * LW = 16 or 48 (mod 64) puts the NG groups' 16-lane reads into different banks
+    static constexpr int LW = NG == 1 ? LW0 : LW0 + ((4 - LW0 % 8) + 8) % 8;
     static constexpr int LWB = (LW0 + 3) & ~3;    // bytes per row of the staged layer tile
+    // wavefronts per SIMD the backward kernel is compiled for: what its LDS tile lets a compute unit hold
+    static constexpr int BWD_WAVES = K <= 25 ? 4 : 3;
     static_assert(NG == 1 || R == 4, "the bank-spreading stride assumes four rows per lane");
 };
 
@@ -1074,16 +1076,22 @@ __global__ __launch_bounds__(64) void code_pattern_fwd_sweep_kernel(
     if (lane == 0) tilekey[((long)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = key;
 }
 
-// LDS bytes of the backward sweep kernel: gradient tile, its copy masked to the current layer,
-// layer tile, per-layer and per-row-per-layer presence flags.
+// LDS bytes of the backward sweep kernel: the tile masked to the current layer and the layer tile.
 template <int K, int R, int CW>
-static size_t sweep_bwd_lds(int L) {
+static size_t sweep_bwd_lds() {
     using S = Sweep<K, R, CW>;
-    return (size_t)S::NR * S::LW * 4 * 2 + (size_t)S::NR * S::LWB + 256 + (size_t)S::NR * L + 4;
+    return (size_t)((S::NR * S::LW + 63) / 64) * 64 * 4 + (size_t)S::NR * S::LWB;     // tile in whole 64-cell slices
 }
 
+// The staged cells (gradient / (max + eps) and layer id) stay in registers for the whole kernel, CPL
+// per lane; a sweep writes them to the one LDS tile masked to its layer.  A second, unmasked LDS copy
+// would halve the wavefronts a compute unit can hold, and that residency -- not the arithmetic --
+// is what bounds this kernel.  Which staged rows hold a pixel of which layer is kept as one 64-bit
+// set of layers per row (lane r: row r), so that the per-sweep row mask is a single ballot and the
+// skip test of an input row is scalar arithmetic.
 template <int K, int R, int CW>
-__global__ __launch_bounds__(64) void code_pattern_bwd_sweep_kernel(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(Sweep<K, R, CW>::BWD_WAVES, Sweep<K, R, CW>::BWD_WAVES)))
+void code_pattern_bwd_sweep_kernel(
     const float* __restrict__ g, const float* __restrict__ out, const uint8_t* __restrict__ layer_u8,
     const float* __restrict__ max_in, const float* __restrict__ psf, int H, int W, int L,
     float* __restrict__ partial, float* __restrict__ g_pat0) {
@@ -1091,42 +1099,57 @@ __global__ __launch_bounds__(64) void code_pattern_bwd_sweep_kernel(
     constexpr int PAD = S::PAD, LW = S::LW, LW0 = S::LW0, LWB = S::LWB, NR = S::NR, NG = S::NG, NRG = R + K - 1;
     constexpr bool PK = S::PK_BWD;
     constexpr int HB = K - 1 - PAD;               // halo rows / columns before the tile
+    constexpr int N = NR * LW, CPL = (N + 63) / 64;               // cells of the LDS tile (padding included), per lane
+    static_assert(NR <= 64, "one lane per staged row");
     extern __shared__ float smem[];
-    float* gt = smem;                                              // [NR][LW] gradient / (max + eps), 0 where masked
-    float* mt = smem + NR * LW;                                    // [NR][LW] the tile masked to the current layer
-    uint8_t* lt = reinterpret_cast<uint8_t*>(mt + NR * LW);        // [NR][LWB] layer of every staged pixel (255: none)
-    uint8_t* present = lt + NR * LWB;                              // [256] layer occurs in the tile
-    uint8_t* rowpres = present + 256;                              // [NR][L] layer occurs in staged row r
+    float* mt = smem;                                              // [NR][LW] the tile masked to the current layer
+    uint8_t* lt = reinterpret_cast<uint8_t*>(mt + CPL * 64);       // [NR][LWB] layer of every staged pixel (255: none)
     const int lane = threadIdx.x, col = lane % CW, grp = lane / CW;
     const int b = blockIdx.z, x0 = blockIdx.x * CW, y0 = blockIdx.y * S::TR;
     const long img = (long)b * H * W;
     const int x = x0 + col, yg = y0 + grp * R;
     const float rden = 1.0f / (max_in[b] + 1e-10f);
 
-    for (int i = lane; i < 64 + NR * L / 4 + 1; i += 64) {        // clear the flags, 4 bytes per lane and step
-        if (i < 64) reinterpret_cast<uint32_t*>(present)[i] = 0u;
-        else if ((i - 64) * 4 < NR * L) reinterpret_cast<uint32_t*>(rowpres)[i - 64] = 0u;
+    // Stage.  Lane `lane` keeps tile cells lane, lane + 64, ... (so a sweep's stores need no address
+    // arithmetic); unconditional loads from clamped addresses, all of a lane's cells in flight.
+    float gv[CPL];
+    uint32_t lv[(CPL + 3) / 4];
+#pragma unroll
+    for (int v = 0; v < (CPL + 3) / 4; ++v) lv[v] = 0u;
+    constexpr int SB = 16;                                         // cells of a lane loaded per batch
+#pragma unroll
+    for (int u0 = 0; u0 < CPL; u0 += SB) {
+        uint8_t lb[SB];
+#pragma unroll
+        for (int u = u0; u < min(u0 + SB, CPL); ++u) {
+            const int i = u * 64 + lane;
+            const int r = min(i / LW, NR - 1), c = min(i % LW, LW0 - 1);
+            const unsigned q = (unsigned)min(max(y0 - HB + r, 0), H - 1) * (unsigned)W + (unsigned)min(max(x0 - HB + c, 0), W - 1);
+            gv[u] = ld_at(g + img, q);
+            lb[u - u0] = ld_at(layer_u8 + img, q);
+        }
+#pragma unroll
+        for (int u = u0; u < min(u0 + SB, CPL); ++u) {
+            const int i = u * 64 + lane;
+            const int r = i / LW, c = i % LW;
+            const int gy = y0 - HB + r, gx = x0 - HB + c;
+            const bool cell = r < NR && c < LW0;
+            const bool ok = cell && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const uint32_t l = ok ? (uint32_t)lb[u - u0] : 255u;
+            gv[u] = ok ? gv[u] * rden : 0.0f;
+            lv[u / 4] |= l << (8 * (u % 4));
+            if (cell) lt[r * LWB + c] = (uint8_t)l;
+        }
+        __builtin_amdgcn_sched_barrier(0);                         // keep the batches apart: registers, not latency, are short here
     }
-    __syncthreads();
-    sweep_stage<NR, LW0>(layer_u8 + img, (unsigned)W, 1u, H, W, x0 - HB, y0 - HB, lane,
-                         [&](int r, int c, uint8_t v, bool ok) {
-                             const uint8_t l = ok ? v : (uint8_t)255;
-                             lt[r * LWB + c] = l;
-                             if (l != 255) {
-                                 present[l] = 1;
-                                 rowpres[r * L + l] = 1;
-                             }
-                         });
-    sweep_stage<NR, LW0>(g + img, (unsigned)W, 1u, H, W, x0 - HB, y0 - HB, lane,
-                         [&](int r, int c, float v, bool ok) { gt[r * LW + c] = ok ? v * rden : 0.0f; });
     // sum of g*out over the pixels this wavefront owns (for the gradient through the per-image maximum)
     float sgo = 0.0f;
 #pragma unroll
     for (int o = 0; o < R; ++o) {
         const int y = yg + o;
         const unsigned q = (unsigned)(min(y, H - 1) * W + min(x, W - 1));
-        const float gv = ld_at(g + img, q), ov = ld_at(out + img, q);
-        sgo = fmaf((y < H && x < W) ? gv : 0.0f, ov, sgo);
+        const float gq = ld_at(g + img, q), ov = ld_at(out + img, q);
+        sgo = fmaf((y < H && x < W) ? gq : 0.0f, ov, sgo);
     }
     sgo = wave_sum(sgo);
     if (lane == 0) partial[((long)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = sgo;
@@ -1139,49 +1162,68 @@ __global__ __launch_bounds__(64) void code_pattern_bwd_sweep_kernel(
         acc[o] = 0.0f;
         acc2[o] = f2{0.0f, 0.0f};
     }
+    constexpr unsigned long long kGroupRows = NG == 4 ? (1ull | 1ull << R | 1ull << 2 * R | 1ull << 3 * R)
+                                            : NG == 2 ? (1ull | 1ull << R) : 1ull;
+    static_assert(NG == 1 || NG == 2 || NG == 4, "row groups per wavefront");
     const float* mine = mt + grp * R * LW + col;                  // this lane's window: rows grp*R .., columns col ..
-    for (int l = 0; l < L; ++l) {
-        if (__builtin_amdgcn_readfirstlane((int)present[l]) == 0) continue;
-        __syncthreads();                          // the previous sweep's reads of mt are done
-        for (int i = lane; i < NR * LW0; i += 64) {
-            const int r = i / LW0, c = i - r * LW0;
-            mt[r * LW + c] = (lt[r * LWB + c] == (uint8_t)l) ? gt[r * LW + c] : 0.0f;
+    for (int base = 0; base < L; base += 64) {                    // layers in sets of 64 (one set unless L > 64)
+        unsigned long long rowset = 0ull;                         // lane r: layers base .. base+63 present in staged row r
+        if (lane < NR) {
+#pragma unroll 8
+            for (int c = 0; c < LW0; ++c) {
+                const unsigned d = (unsigned)lt[lane * LWB + c] - (unsigned)base;
+                rowset |= d < 64u ? 1ull << d : 0ull;
+            }
         }
-        __syncthreads();
-        // Row r of a group's window, column col+e is source (yg-HB+r, x-HB+e); it reaches output row o
-        // through PSF row K-1-(r-o) and PSF column K-1-e.  Rows R-1 .. K-1 feed all R output rows
-        // (straight-line code, see the forward kernel); the first and last R-1 rows take the branchy form.
-        auto row_step = [&](int r, auto full) {
-            constexpr bool FULL = decltype(full)::value;
-            int any = 0;
+        unsigned long long todo = rowset;
 #pragma unroll
-            for (int gq = 0; gq < NG; ++gq) any |= (int)rowpres[(gq * R + r) * L + l];
-            if (__builtin_amdgcn_readfirstlane(any) == 0) return;
-            float in[K];
+        for (int o = 32; o > 0; o >>= 1) todo |= __shfl_xor(todo, o, 64);
+        todo = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(todo >> 32)) << 32) |
+               (unsigned)__builtin_amdgcn_readfirstlane((int)todo);
+        while (todo != 0ull) {
+            const int d = __builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            const int l = base + d;
+            const unsigned long long rows = __ballot((rowset >> d) & 1ull);   // staged rows with a pixel of layer l
+            __syncthreads();                      // the previous sweep's reads of the tile are done
 #pragma unroll
-            for (int e = 0; e < K; ++e) in[e] = mine[r * LW + e];
-            // PSF row K-1-(r-o) of layer l sits o*K floats after wbase: constant offsets for the scalar loads
-            const float* wbase = psf + ((long)l * K + (K - 1 - r)) * K;
+            for (int u = 0; u < CPL; ++u) {
+                const bool on = ((lv[u / 4] >> (8 * (u % 4))) & 255u) == (unsigned)l;
+                mt[u * 64 + lane] = on ? gv[u] : 0.0f;
+            }
+            __syncthreads();
+            // Row r of a group's window, column col+e is source (yg-HB+r, x-HB+e); it reaches output row o
+            // through PSF row K-1-(r-o) and PSF column K-1-e.  Rows R-1 .. K-1 feed all R output rows
+            // (straight-line code, see the forward kernel); the first and last R-1 rows take the branchy form.
+            auto row_step = [&](int r, auto full) {
+                constexpr bool FULL = decltype(full)::value;
+                if (((rows >> r) & kGroupRows) == 0ull) return;   // no group has a pixel of this layer in its row r
+                float in[K];
 #pragma unroll
-            for (int o = 0; o < R; ++o) {
-                const int d = r - o;
-                if (FULL || (d >= 0 && d < K)) {
-                    const float* wr = wbase + o * K;
-                    if (PK) {
+                for (int e = 0; e < K; ++e) in[e] = mine[r * LW + e];
+                // PSF row K-1-(r-o) of layer l sits o*K floats after wbase: constant offsets for the scalar loads
+                const float* wbase = psf + ((long)l * K + (K - 1 - r)) * K;
 #pragma unroll
-                        for (int e = 0; e + 1 < K; e += 2)
-                            acc2[o] = __builtin_elementwise_fma(f2{wr[K - 1 - e], wr[K - 2 - e]}, f2{in[e], in[e + 1]}, acc2[o]);
-                        acc2[o].x = fmaf(wr[0], in[K - 1], acc2[o].x);    // K is odd
-                    } else {
+                for (int o = 0; o < R; ++o) {
+                    const int dd = r - o;
+                    if (FULL || (dd >= 0 && dd < K)) {
+                        const float* wr = wbase + o * K;
+                        if (PK) {
 #pragma unroll
-                        for (int e = 0; e < K; ++e) acc[o] = fmaf(wr[K - 1 - e], in[e], acc[o]);
+                            for (int e = 0; e + 1 < K; e += 2)
+                                acc2[o] = __builtin_elementwise_fma(f2{wr[K - 1 - e], wr[K - 2 - e]}, f2{in[e], in[e + 1]}, acc2[o]);
+                            acc2[o].x = fmaf(wr[0], in[K - 1], acc2[o].x);    // K is odd
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < K; ++e) acc[o] = fmaf(wr[K - 1 - e], in[e], acc[o]);
+                        }
                     }
                 }
-            }
-        };
-        for (int r = 0; r < R - 1; ++r) row_step(r, std::false_type{});
-        for (int r = R - 1; r < K; ++r) row_step(r, std::true_type{});
-        for (int r = K; r < NRG; ++r) row_step(r, std::false_type{});
+            };
+            for (int r = 0; r < R - 1; ++r) row_step(r, std::false_type{});
+            for (int r = R - 1; r < K; ++r) row_step(r, std::true_type{});
+            for (int r = K; r < NRG; ++r) row_step(r, std::false_type{});
+        }
     }
 #pragma unroll
     for (int o = 0; o < R; ++o) {
@@ -1396,7 +1438,7 @@ extern "C" int fc3d_code_pattern_bwd(void* stream, const float* g_out, const flo
 #undef FC3D_BWD_ROLL_CASE
 #define FC3D_BWD_SWEEP_CASE(KV)                                                                                  \
     if (Kw == KV) {                                                                                              \
-        const size_t slds = sweep_bwd_lds<KV, kSweepRows, kSweepCols>(L);                                        \
+        const size_t slds = sweep_bwd_lds<KV, kSweepRows, kSweepCols>();                                         \
         const dim3 gsw(cdiv(W, kSweepCols), cdiv(H, kSweepTileRows), B);                                         \
         FC3D_LAUNCH("code_pattern_bwd", (code_pattern_bwd_sweep_kernel<KV, kSweepRows, kSweepCols>), gsw,        \
                     dim3(64), slds, s, g_out, out, layer_u8, max_in, psf, H, W, L, partial, g_pat0);             \

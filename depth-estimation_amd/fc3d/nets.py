@@ -45,39 +45,52 @@ class Up(nn.Module):
 
 
 class UNet(nn.Module):
-    def __init__(self, out_channels: int, lo, hi):
+    """Sub-modules carry the reference's attribute names (down<l>_<i>, up<l>_0 for the up-convolution,
+    up<l>_1/2 for the decoder pair, up1_3 for the head; network_pytorch.py:64-101, 143-180), so a
+    state_dict written by the reference loads here with strict=True and the other way round.  The
+    output range is a pair of persistent buffers under the names given in `range_names`
+    (xy_min / xy_max, network_pytorch.py:104-105) or, with range_names=None, kept out of the
+    state_dict like the plain floats of network_pytorch.py:183-184."""
+
+    def __init__(self, out_channels: int, lo, hi, range_names=None):
         super().__init__()
-        self.enc = nn.ModuleList()
+        self.levels = len(WIDTHS)
         cin = 1
-        for w in WIDTHS:
-            self.enc.append(nn.Sequential(ConvBN(cin, w), ConvBN(w, w)))
+        for lvl, w in enumerate(WIDTHS, 1):
+            self.add_module(f"down{lvl}_1", ConvBN(cin, w))
+            self.add_module(f"down{lvl}_2", ConvBN(w, w))
             cin = w
-        self.up = nn.ModuleList()
-        self.dec = nn.ModuleList()
-        for w in reversed(WIDTHS[:-1]):
-            self.up.append(Up(2 * w, w))
-            self.dec.append(nn.Sequential(ConvBN(2 * w, w), ConvBN(w, w)))
-        self.head = ConvBN(WIDTHS[0], out_channels, k=1, relu=False)
-        self.register_buffer("lo", torch.as_tensor(lo, dtype=torch.float32).reshape(1, -1, 1, 1))
-        self.register_buffer("hi", torch.as_tensor(hi, dtype=torch.float32).reshape(1, -1, 1, 1))
+        for lvl in range(self.levels - 1, 0, -1):
+            w = WIDTHS[lvl - 1]
+            self.add_module(f"up{lvl}_0", Up(2 * w, w))
+            self.add_module(f"up{lvl}_1", ConvBN(2 * w, w))
+            self.add_module(f"up{lvl}_2", ConvBN(w, w))
+        self.add_module("up1_3", ConvBN(WIDTHS[0], out_channels, k=1, relu=False))
+        self._range = range_names or ("_lo", "_hi")
+        for name, v in zip(self._range, (lo, hi)):
+            self.register_buffer(name, torch.as_tensor(np.asarray(v), dtype=torch.float32).reshape(1, -1, 1, 1),
+                                 persistent=range_names is not None)
 
     def forward(self, x):
         x = x.permute(0, 3, 1, 2)
+        m = self._modules
         skips = []
-        for i, blk in enumerate(self.enc):
-            if i:
+        for lvl in range(1, self.levels + 1):
+            if lvl > 1:
                 x = F.max_pool2d(x, 2)
-            x = blk(x)
+            x = m[f"down{lvl}_2"](m[f"down{lvl}_1"](x))
             skips.append(x)
-        for up, dec, skip in zip(self.up, self.dec, reversed(skips[:-1])):
-            x = dec(torch.cat([up(x), skip], dim=1))
-        out = torch.sigmoid(self.head(x)) * (self.hi - self.lo) + self.lo
+        for lvl in range(self.levels - 1, 0, -1):
+            x = torch.cat([m[f"up{lvl}_0"](x), skips[lvl - 1]], dim=1)
+            x = m[f"up{lvl}_2"](m[f"up{lvl}_1"](x))
+        lo, hi = (self._buffers[n] for n in self._range)
+        out = torch.sigmoid(m["up1_3"](x)) * (hi - lo) + lo
         return out.permute(0, 2, 3, 1)
 
 
 def UNet_xy() -> UNet:
     """x/z, y/z regressor; network_pytorch.py:56-132."""
-    return UNet(2, XY_MIN, XY_MAX)
+    return UNet(2, XY_MIN, XY_MAX, range_names=("xy_min", "xy_max"))
 
 
 def UNet_z() -> UNet:

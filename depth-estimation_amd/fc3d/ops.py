@@ -395,11 +395,16 @@ class WarpP2CFn(torch.autograd.Function):
 
 
 class PointsFn(torch.autograd.Function):
-    """points_in_camera_coords; geometry_pytorch.py:44-65.  Returns [B,H,W,4]."""
+    """points_in_camera_coords; geometry_pytorch.py:44-65.  Returns [B,H,W,4].
+    Differentiable in z_map only: the rays are constants of the camera in the reference
+    (numpy arrays, geometry_pytorch.py:54-57), and rays that require a gradient are refused
+    rather than silently given none."""
 
     @staticmethod
     def forward(ctx, z_map, ray_x, ray_y, ray_dense):
         dev = _need_gpu(z_map, ray_x, ray_y, ray_dense)
+        if any(ctx.needs_input_grad[1:]):
+            raise NotImplementedError("points_in_camera_coords: no gradient w.r.t. the rays; detach them")
         if z_map.dim() != 4 or z_map.shape[-1] != 1:
             raise RuntimeError(f"z_map must be [B,H,W,1], got {tuple(z_map.shape)}")
         z = _dense(z_map)
@@ -419,14 +424,14 @@ class PointsFn(torch.autograd.Function):
         with _on_device(dev):
             _check(_lib.fc3d_points_fwd(_stream(), z.data_ptr(), ptr(ray_x), ptr(ray_y), ptr(ray_dense), sb, B, H, W,
                                         out.data_ptr()), "fc3d_points_fwd")
-        ctx.rays = (ray_x, ray_y, ray_dense, sb)
-        ctx.shape = (B, H, W)
+        ctx.save_for_backward(ray_x, ray_y, ray_dense)
+        ctx.shape = (B, H, W, sb)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
-        ray_x, ray_y, ray_dense, sb = ctx.rays
-        B, H, W = ctx.shape
+        ray_x, ray_y, ray_dense = ctx.saved_tensors
+        B, H, W, sb = ctx.shape
         g = _dense(g_out)
         gz = torch.empty((B, H, W, 1), dtype=torch.float32, device=g.device)
         ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731

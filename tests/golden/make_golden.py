@@ -443,6 +443,28 @@ def g9_callers(ref_dir):
     save("g9_callers", **blob)
 
 
+def g10_nets(N):
+    """network_pytorch.py:56-211: state_dict keys and shapes of the two U-Nets, and what they return for a
+    small input with seeded initial weights (training mode first, then evaluation mode with the running
+    statistics that one training pass left).  The weights themselves (69 MB) are not stored: the same seed
+    and the same order of construction reproduce them, and per-tensor sums are stored to prove it."""
+    blob = {}
+    x = t(np.random.RandomState(101).uniform(0, 1, (2, 32, 48, 1)).astype(np.float32))
+    for tag, cls in (("xy", N.UNet_xy), ("z", N.UNet_z)):
+        torch.manual_seed(77)
+        net = cls()
+        sd = net.state_dict()
+        blob[tag + "_keys"] = np.array(list(sd.keys()))
+        blob[tag + "_shapes"] = np.array([",".join(map(str, v.shape)) for v in sd.values()])
+        blob[tag + "_sums"] = np.array([float(v.double().sum()) for v in sd.values()])
+        net.train()
+        blob[tag + "_out_train"] = net(x)
+        net.eval()
+        with torch.no_grad():
+            blob[tag + "_out_eval"] = net(x)
+    save("g10_nets", x=x, **blob)
+
+
 def g0_rays(G):
     """pixel_to_ray_array / pixel_to_ray / get_intrinsic / z2pointcloud constants."""
     r = G.pixel_to_ray_array(width=24, height=10)
@@ -465,6 +487,11 @@ def main():
     if args.only == "g9":
         g9_callers(args.ref)
         return
+    if args.only == "g10":
+        import network_pytorch as N
+        assert N.__file__.startswith(args.ref)
+        g10_nets(N)
+        return
     g0_rays(G)
     g1_layers(O)
     g2_code_pattern(O)
@@ -477,6 +504,9 @@ def main():
     assert U.__file__.startswith(args.ref)
     g8_utils(U)
     g9_callers(args.ref)
+    import network_pytorch as N
+    assert N.__file__.startswith(args.ref)
+    g10_nets(N)
 
 
 if __name__ == "__main__":

@@ -158,6 +158,39 @@ def test_unets_match_reference_parameter_count():
     assert out.shape == (1, 32, 48, 2)
 
 
+@pytest.mark.parametrize("tag", ["xy", "z"])
+def test_unets_load_reference_checkpoints(tag, tmp_path, golden):
+    """State-dict keys, shapes, seeded initial weights and outputs of the U-Nets against the reference's
+    (network_pytorch.py:56-211, recorded in g10_nets.npz), and a checkpoint round trip through the
+    weights-only loader in the layout train_pytorch.py:401-407 writes and :257-259 reads."""
+    from fc3d import nets
+    g = golden("g10_nets")
+    torch.manual_seed(77)
+    net = {"xy": nets.UNet_xy, "z": nets.UNet_z}[tag]()
+    sd = net.state_dict()
+    assert list(sd.keys()) == [str(k) for k in g[tag + "_keys"]]
+    assert [",".join(map(str, v.shape)) for v in sd.values()] == [str(v) for v in g[tag + "_shapes"]]
+    sums = np.array([float(v.double().sum()) for v in sd.values()])
+    assert np.allclose(sums, g[tag + "_sums"], rtol=1e-12, atol=1e-12)      # same seed, same order: same weights
+    x = torch.from_numpy(g["x"])
+    net.train()
+    out = net(x)
+    assert float((out - torch.from_numpy(g[tag + "_out_train"])).abs().max()) <= 1e-6
+    net.eval()
+    with torch.no_grad():
+        out = net(x)
+    assert float((out - torch.from_numpy(g[tag + "_out_eval"])).abs().max()) <= 1e-6
+    path = str(tmp_path / "ckpt.pth")
+    torch.save({"epoch": 3, "model_" + tag: net.state_dict()}, path)
+    ck = torch.load(path, map_location="cpu", weights_only=True)
+    torch.manual_seed(1)
+    other = {"xy": nets.UNet_xy, "z": nets.UNet_z}[tag]()
+    other.load_state_dict(ck["model_" + tag], strict=True)
+    other.eval()
+    with torch.no_grad():
+        assert torch.equal(other(x), out)
+
+
 def test_synthetic_scene_is_deterministic_and_in_range():
     from fc3d import synth
     a = synth.make_scene(2, 32, 48, 5)
