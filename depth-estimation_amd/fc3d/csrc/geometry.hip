@@ -15,36 +15,46 @@ namespace fc3d {
 // ---------------------------------------------------------------------------------------
 // per-sample matrices
 // ---------------------------------------------------------------------------------------
+// Gauss-Jordan with partial pivoting in fp64, rounded to fp32 once by the caller.  Every loop
+// bound and every index is a compile-time constant (the pivot row is brought up by compare-and-swap
+// of whole rows instead of an indexed exchange), so the 4 x 8 tableau lives in registers: an
+// indexed private array would sit in scratch memory and give every lane of the launch a scratch
+// allocation for the sake of the B lanes that invert.
 __device__ inline bool invert4(const float* a, double* inv) {
     double m[4][8];
+#pragma unroll
     for (int i = 0; i < 4; ++i)
+#pragma unroll
         for (int j = 0; j < 4; ++j) {
             m[i][j] = (double)a[i * 4 + j];
             m[i][4 + j] = (i == j) ? 1.0 : 0.0;
         }
+#pragma unroll
     for (int c = 0; c < 4; ++c) {
-        int p = c;
-        double best = fabs(m[c][c]);
-        for (int r = c + 1; r < 4; ++r)
-            if (fabs(m[r][c]) > best) {
-                best = fabs(m[r][c]);
-                p = r;
-            }
-        if (p != c)
+#pragma unroll
+        for (int r = c + 1; r < 4; ++r) {           // the largest |m[r][c]|, r >= c, ends up in row c (first one on ties)
+            const bool up = fabs(m[r][c]) > fabs(m[c][c]);
+#pragma unroll
             for (int j = 0; j < 8; ++j) {
-                double t = m[c][j];
-                m[c][j] = m[p][j];
-                m[p][j] = t;
+                const double t = m[c][j];
+                m[c][j] = up ? m[r][j] : t;
+                m[r][j] = up ? t : m[r][j];
             }
+        }
         const double d = 1.0 / m[c][c];
+#pragma unroll
         for (int j = 0; j < 8; ++j) m[c][j] *= d;
+#pragma unroll
         for (int r = 0; r < 4; ++r)
             if (r != c) {
                 const double f = m[r][c];
+#pragma unroll
                 for (int j = 0; j < 8; ++j) m[r][j] -= f * m[c][j];
             }
     }
+#pragma unroll
     for (int i = 0; i < 4; ++i)
+#pragma unroll
         for (int j = 0; j < 4; ++j) inv[i * 4 + j] = m[i][4 + j];
     return true;
 }
