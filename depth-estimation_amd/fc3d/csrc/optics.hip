@@ -927,6 +927,9 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 template <int K, int R, int CW>
 struct Sweep {
     static constexpr bool PK_FWD = K >= 15, PK_BWD = K >= 13;
+    // forward loop order: PSF-row-major with the input rows rotating through registers from 15x15 on
+    // (measured at 8x512x512: 15x15 43 -> 41 us, 23x23 78 -> 68, 33x33 148 -> 124; 9x9 .. 13x13 lose 1-3 us)
+    static constexpr bool PSF_ROW_MAJOR_FWD = K >= 15;
     static constexpr int PAD = (K - 1) / 2;
     static constexpr int NG = 64 / CW;            // row groups of lanes
     static constexpr int TR = NG * R;             // output rows per wavefront
@@ -963,6 +966,78 @@ __device__ __forceinline__ void sweep_stage(const T* __restrict__ plane, unsigne
                 const int r = i / LW0, c = i - r * LW0;
                 const int gy = y_first + r, gx = x_first + c;
                 put(r, c, v[u], gy >= 0 && gy < H && gx >= 0 && gx < W);
+            }
+        }
+    }
+}
+
+// One sweep of one layer: acc[o] += sum over PSF rows dy in [dy_lo, dy_hi] and columns e of
+// w(dy, e) * tile[dy + o][e], for the R output rows o of a lane.  `mine` points at the lane's window
+// in the LDS tile (row stride LW), `wl` at the K x K PSF of the layer; FLIP reads the PSF mirrored in
+// both directions (the backward form).  PSF-row-major: an iteration loads ONE PSF row (K scalar
+// registers) and ONE new input row (K vector registers) and uses them with the R-1 input rows of
+// the previous iterations, which stay in registers -- unrolled by R so that the rotation is a
+// renaming, not a copy.  (Input-row-major order needs all R PSF rows of an input row at once:
+// 4 K scalar loads per row, no room to keep them across rows in 100 scalar registers, and one
+// full wait for LDS and scalar loads together per row.)  Per accumulator the order of additions is
+// dy ascending, then e ascending (even and odd e apart when packed), as in the other kernels.
+template <int K, int R, int LW, bool PK, bool FLIP>
+__device__ __forceinline__ void sweep_core(const float* mine, const float* __restrict__ wl, int dy_lo, int dy_hi,
+                                           float (&acc)[R], f2 (&acc2)[R]) {
+    static_assert(R == 4, "the rotation is unrolled for four rows per lane");
+    constexpr int NRG = R + K - 1;
+    float X[R][K];
+    float Wt[1][K];
+    auto load_row = [&](float (&x)[K], int r) {
+#pragma unroll
+        for (int e = 0; e < K; ++e) x[e] = mine[r * LW + e];
+    };
+    auto load_psf = [&](float (&w)[K], int dy) {
+        const float* wr = wl + (FLIP ? K - 1 - dy : dy) * K;
+#pragma unroll
+        for (int e = 0; e < K; ++e) w[e] = FLIP ? wr[K - 1 - e] : wr[e];
+    };
+    // two output rows at a time, their accumulator chains interleaved (a packed multiply-add that
+    // reads the result of the one before it costs a wait state)
+    auto fma_pair = [&](int oa, const float (&w)[K], const float (&xa)[K], const float (&xb)[K]) {
+        if (PK) {
+#pragma unroll
+            for (int e = 0; e + 1 < K; e += 2) {
+                acc2[oa] = __builtin_elementwise_fma(f2{w[e], w[e + 1]}, f2{xa[e], xa[e + 1]}, acc2[oa]);
+                acc2[oa + 1] = __builtin_elementwise_fma(f2{w[e], w[e + 1]}, f2{xb[e], xb[e + 1]}, acc2[oa + 1]);
+            }
+            acc2[oa].x = fmaf(w[K - 1], xa[K - 1], acc2[oa].x);          // K is odd
+            acc2[oa + 1].x = fmaf(w[K - 1], xb[K - 1], acc2[oa + 1].x);
+        } else {
+#pragma unroll
+            for (int e = 0; e < K; ++e) {
+                acc[oa] = fmaf(w[e], xa[e], acc[oa]);
+                acc[oa + 1] = fmaf(w[e], xb[e], acc[oa + 1]);
+            }
+        }
+    };
+    // x0..x2 hold input rows dy..dy+2; x3 is free and receives row dy+3
+    auto step = [&](int dy, float (&x0)[K], float (&x1)[K], float (&x2)[K], float (&x3)[K]) {
+        load_row(x3, dy + R - 1);
+        load_psf(Wt[0], dy);
+        fma_pair(0, Wt[0], x0, x1);
+        fma_pair(2, Wt[0], x2, x3);
+    };
+    const int d0 = dy_lo & ~(R - 1);
+    load_row(X[0], d0);
+    load_row(X[1], d0 + 1);
+    load_row(X[2], d0 + 2);
+    for (int d4 = d0; d4 <= dy_hi; d4 += R) {
+        if (d4 + R <= K) {
+            step(d4, X[0], X[1], X[2], X[3]);
+            step(d4 + 1, X[1], X[2], X[3], X[0]);
+            step(d4 + 2, X[2], X[3], X[0], X[1]);
+            step(d4 + 3, X[3], X[0], X[1], X[2]);
+        } else {                                   // the last K % 4 PSF rows (K is odd: one or three)
+            step(d4, X[0], X[1], X[2], X[3]);
+            if (K % R == 3) {
+                step(d4 + 1, X[1], X[2], X[3], X[0]);
+                step(d4 + 2, X[2], X[3], X[0], X[1]);
             }
         }
     }
@@ -1008,10 +1083,6 @@ __global__ __launch_bounds__(64) void code_pattern_fwd_sweep_kernel(
         if (cand == 0x7fffffff) break;
         last = cand;
         const int l = __builtin_amdgcn_readfirstlane(cand);     // the layer of this sweep, in a scalar register
-        unsigned rows = 0;                                       // row slots in which some lane has a pixel of layer l
-#pragma unroll
-        for (int o = 0; o < R; ++o)
-            if (__ballot(lay[o] == l) != 0ull) rows |= 1u << o;
         float acc[R];                                            // one of the two sets is used, per PK
         f2 acc2[R];
 #pragma unroll
@@ -1019,40 +1090,48 @@ __global__ __launch_bounds__(64) void code_pattern_fwd_sweep_kernel(
             acc[o] = 0.0f;
             acc2[o] = f2{0.0f, 0.0f};
         }
-        // Input rows R-1 .. K-1 feed all R output rows: that part is straight-line code (R scalar
-        // loads of a PSF row, R*K multiply-adds) so that the loads run ahead of the arithmetic; the
-        // first and last R-1 input rows feed fewer output rows and take the branchy form.
-        auto row_step = [&](int r, auto full) {
-            constexpr bool FULL = decltype(full)::value;
-            if (!FULL) {
-                const int lo = max(r - (K - 1), 0), hi = min(r, R - 1);   // output rows that input row r feeds
-                if ((rows & ((2u << hi) - 1u) & ~((1u << lo) - 1u)) == 0u) return;
-            }
-            float in[K];
+        if constexpr (S::PSF_ROW_MAJOR_FWD) {
+            sweep_core<K, R, LW, PK, false>(mine, psf + (long)l * K * K, 0, K - 1, acc, acc2);
+        } else {
+            unsigned rows = 0;                                       // row slots in which some lane has a pixel of layer l
 #pragma unroll
-            for (int dx = 0; dx < K; ++dx) in[dx] = mine[r * LW + dx];
-            // PSF row dy = r - o of layer l sits (R-1-o)*K floats after wbase: constant offsets for the scalar loads
-            const float* wbase = psf + ((long)l * K + (r - (R - 1))) * K;
+            for (int o = 0; o < R; ++o)
+                if (__ballot(lay[o] == l) != 0ull) rows |= 1u << o;
+            // Input rows R-1 .. K-1 feed all R output rows: that part is straight-line code (R scalar
+            // loads of a PSF row, R*K multiply-adds) so that the loads run ahead of the arithmetic; the
+            // first and last R-1 input rows feed fewer output rows and take the branchy form.
+            auto row_step = [&](int r, auto full) {
+                constexpr bool FULL = decltype(full)::value;
+                if (!FULL) {
+                    const int lo = max(r - (K - 1), 0), hi = min(r, R - 1);   // output rows that input row r feeds
+                    if ((rows & ((2u << hi) - 1u) & ~((1u << lo) - 1u)) == 0u) return;
+                }
+                float in[K];
 #pragma unroll
-            for (int o = 0; o < R; ++o) {
-                const int dy = r - o;
-                if (FULL || (((rows >> o) & 1u) && dy >= 0 && dy < K)) {
-                    const float* wr = wbase + (R - 1 - o) * K;
-                    if (PK) {
+                for (int dx = 0; dx < K; ++dx) in[dx] = mine[r * LW + dx];
+                // PSF row dy = r - o of layer l sits (R-1-o)*K floats after wbase: constant offsets for the scalar loads
+                const float* wbase = psf + ((long)l * K + (r - (R - 1))) * K;
 #pragma unroll
-                        for (int dx = 0; dx + 1 < K; dx += 2)
-                            acc2[o] = __builtin_elementwise_fma(f2{wr[dx], wr[dx + 1]}, f2{in[dx], in[dx + 1]}, acc2[o]);
-                        acc2[o].x = fmaf(wr[K - 1], in[K - 1], acc2[o].x);  // K is odd
-                    } else {
+                for (int o = 0; o < R; ++o) {
+                    const int dy = r - o;
+                    if (FULL || (((rows >> o) & 1u) && dy >= 0 && dy < K)) {
+                        const float* wr = wbase + (R - 1 - o) * K;
+                        if (PK) {
 #pragma unroll
-                        for (int dx = 0; dx < K; ++dx) acc[o] = fmaf(wr[dx], in[dx], acc[o]);
+                            for (int dx = 0; dx + 1 < K; dx += 2)
+                                acc2[o] = __builtin_elementwise_fma(f2{wr[dx], wr[dx + 1]}, f2{in[dx], in[dx + 1]}, acc2[o]);
+                            acc2[o].x = fmaf(wr[K - 1], in[K - 1], acc2[o].x);  // K is odd
+                        } else {
+#pragma unroll
+                            for (int dx = 0; dx < K; ++dx) acc[o] = fmaf(wr[dx], in[dx], acc[o]);
+                        }
                     }
                 }
-            }
-        };
-        for (int r = 0; r < R - 1; ++r) row_step(r, std::false_type{});
-        for (int r = R - 1; r < K; ++r) row_step(r, std::true_type{});
-        for (int r = K; r < NRG; ++r) row_step(r, std::false_type{});
+            };
+            for (int r = 0; r < R - 1; ++r) row_step(r, std::false_type{});
+            for (int r = R - 1; r < K; ++r) row_step(r, std::true_type{});
+            for (int r = K; r < NRG; ++r) row_step(r, std::false_type{});
+        }
 #pragma unroll
         for (int o = 0; o < R; ++o)
             if (lay[o] == l) res[o] = PK ? acc2[o].x + acc2[o].y : acc[o];
