@@ -157,6 +157,23 @@ def test_c4_large_kernels(env, monkeypatch):
         _, _, mx, _ = env["ops"].CodePatternFn.apply(t["pat"], t["z_p"], O._device_psfs(t["pat"].device), O._layer_grid(L), True)
         got = Ip[0, y0 + m:y0 + h - m, x0 + m:x0 + w - m, 0].cpu().numpy() * (float(mx[0]) + 1e-10)
         assert rel_err(got, raw_r[0, m:h - m, m:w - m, 0].numpy()) < TOL, K
+        # backward of codePattern alone on the same crop: a pattern pixel K//2 inside the crop collects from
+        # outputs that all lie in the crop, so the oracle's gradient of sum(g * raw / (max + eps)) there is the
+        # full-size one -- provided the footprint of the gradient through the per-image maximum (K x K around
+        # the brightest pixel of the image) stays out of the crop, which is asserted
+        pat = t["pat"].clone().requires_grad_(True)
+        Ip_b = O.codePattern(pat, t["z_p"], n_layers=L)
+        Ip_b.backward(t["g"])
+        am = int(Ip_b[0].flatten().argmax())
+        ay, ax = am // W, am % W
+        assert not (y0 - K <= ay < y0 + h + K and x0 - K <= ax < x0 + w + K), (ay, ax)
+        pc_b = pc.clone().requires_grad_(True)
+        _, raw_b, _ = orc.codePattern(pc_b, t["z_p"][0:1, y0:y0 + h, x0:x0 + w].cpu(), wl["psfs"], True, return_parts=True)
+        raw_b.backward(t["g"][0:1, y0:y0 + h, x0:x0 + w].cpu() / (float(mx[0]) + 1e-10))
+        gref = pc_b.grad[0, m:h - m, m:w - m, 0].numpy()
+        ggot = pat.grad[0, y0 + m:y0 + h - m, x0 + m:x0 + w - m, 0].cpu().numpy()
+        assert np.abs(gref).max() > 0
+        assert rel_err(ggot, gref) < TOL and rel_err_elem(ggot, gref) < TOL, K
 
 
 @pytest.mark.parametrize("name", ["C2", "C5"])
