@@ -51,6 +51,22 @@ __device__ __forceinline__ volatile FC3D_LDS T* lds_ptr(T* p) {
     return (volatile FC3D_LDS T*)p;
 }
 
+// Workgroups of a launch go to the eight XCDs round robin in launch order, and each XCD has its own
+// L2.  block_x() renumbers blockIdx.x so that XCD k works through the k-th contiguous eighth of the
+// x range: neighbouring tiles (which share halo rows or gather the same source lines) then meet in
+// one L2 instead of being fetched once per XCD.
+#ifndef FC3D_XCD_REMAP
+#define FC3D_XCD_REMAP 1
+#endif
+__device__ __forceinline__ unsigned block_x() {
+#if FC3D_XCD_REMAP
+    const unsigned x = blockIdx.x, q = gridDim.x >> 3;
+    return x < (q << 3) ? (x & 7u) * q + (x >> 3) : x;
+#else
+    return blockIdx.x;
+#endif
+}
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline bool aligned4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0; }
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -14,8 +14,12 @@ constexpr int NT = 256;
 constexpr int PPL = 2;
 constexpr int PX_PER_BLOCK = NT * PPL;
 
+// XCD: renumber the workgroups so that each XCD walks through a contiguous part of the image.  It pays
+// where neighbouring workgroups re-read each other's lines (the sampler's gather: 329 -> 279 MB per
+// launch at 32x512x512, -1.2 us); the splat only streams, and measured 0.9 us slower with it.
+template <bool XCD = true>
 __device__ __forceinline__ long lane_first_pixel() {
-    return (long)blockIdx.x * PX_PER_BLOCK + (threadIdx.x >> 6) * (64 * PPL) + (threadIdx.x & 63);
+    return (long)(XCD ? block_x() : blockIdx.x) * PX_PER_BLOCK + (threadIdx.x >> 6) * (64 * PPL) + (threadIdx.x & 63);
 }
 
 // Row of T times a column.  torch.matmul([B,4,4],[B,4,HW]) runs a k-ordered fused
@@ -199,7 +203,7 @@ __device__ __forceinline__ void emit_tap_index(const TapIndex& ix, const int x0[
                                                const bool on[PPL]) {
     __shared__ int2 s_runbox[RUN_PER_GROUP];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const long run = (long)blockIdx.x * RUN_PER_GROUP + wv;
+    const long run = (long)block_x() * RUN_PER_GROUP + wv;
     int wmin = kBoxEmptyMin, wmax = kBoxEmptyMax;
 #pragma unroll
     for (int i = 0; i < PPL; ++i) {
@@ -230,7 +234,7 @@ __device__ __forceinline__ void emit_tap_index(const TapIndex& ix, const int x0[
             gmin = pk_min(gmin, s_runbox[w].x);
             gmax = pk_max(gmax, s_runbox[w].y);
         }
-        ix.group[blockIdx.x] = make_int2(gmin, gmax);
+        ix.group[block_x()] = make_int2(gmin, gmax);
     }
 }
 

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(NT) void project_kernel(const float* __restrict__ c
                                                      float* __restrict__ grid, uint8_t* __restrict__ mask_u8) {
     const int b = blockIdx.y;
     const long HW = (long)H * W;
-    const long p0 = lane_first_pixel();
+    const long p0 = lane_first_pixel<false>();
     const float* T = Tm + (long)b * 16;
     const float* cb = coord + (long)b * sb;
     float c[PPL][4];

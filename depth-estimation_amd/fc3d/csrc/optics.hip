@@ -522,7 +522,7 @@ __global__ __launch_bounds__(NT) void code_pattern_bwd_roll_kernel(
 
     // (row block, strip) pairs are numbered along one grid axis, so that only the last workgroup
     // of an image can hold wavefronts without work
-    const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * (NT / 64) + wv);   // the same for all lanes: keep it scalar
+    const int wid = __builtin_amdgcn_readfirstlane(block_x() * (NT / 64) + wv);   // the same for all lanes: keep it scalar
     const long pidx = (long)b * (gridDim.x * (NT / 64)) + wid;
     const int strip = wid % nstrips;
     const int xs = strip * SW;                    // first output column of this wavefront's strip
@@ -654,7 +654,7 @@ void code_pattern_fwd_roll_kernel(
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const long img = (long)b * H * W;
     // (row block, strip) pairs along one grid axis: no idle strips; the same for all lanes, so kept scalar
-    const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * (NT / 64) + wv);
+    const int wid = __builtin_amdgcn_readfirstlane(block_x() * (NT / 64) + wv);
     const long kidx = (long)b * (gridDim.x * (NT / 64)) + wid;
     const int strip = wid % nstrips;
     const int xs = strip * SW;
