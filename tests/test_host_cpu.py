@@ -48,6 +48,12 @@ def test_cabi_exports_every_declared_symbol():
     assert lib.fc3d_reflectance_fwd(None, one, -1, one, 1, 8, 8, one) == -1            # negative batch stride
     assert lib.fc3d_reproj_loss_fwd(None, one, one, None, one, one, one, one, one, 1, 8, 8, 8, 8, one, one, one) == -1
     assert lib.fc3d_reproj_loss_fwd_static(None, one, one, None, one, one, one, one, one, 1, 8, 8, 8, 8, one, one) == -1
+    # one image too large for the 32-bit per-image byte offsets of the sampling kernels: refused, not wrapped
+    big = (32768, 16384)                        # 2^29 pixels
+    assert lib.fc3d_warp_p2c_fwd(None, one, one, 0, 0, 0, 0, one, 0, 0, 0, 0, one, one, 1, *big, one, one + 8, one + 16,
+                                 one, 0, None) == -2
+    assert lib.fc3d_capture_warp_fwd(None, one, one, one, one, one, one, one, 1, *big, one, one, one, 0, None, None) == -2
+    assert lib.fc3d_bilinear_bwd_img(None, one, one + 8, None, 1, 8, 8, 1, *big, None, 0, one) == -2
     # more partial sums than the library's static array holds: refused before any device work
     assert lib.fc3d_reproj_loss_fwd_static(None, one, one, one, one, one, one, one, one, 300, 512, 512, 512, 512,
                                            one, one) == -4
