@@ -47,6 +47,8 @@ SIGNATURES = {
     "fc3d_visible_mask": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P]),
     "fc3d_warp_p2c_fwd": (c_int, [P, P, P, I64, I64, I64, I64, P, I64, I64, I64, I64, P, P, c_int, c_int, c_int,
                                   P, P, P, P, c_int, P]),
+    "fc3d_warp_p2c_pose_fwd": (c_int, [P, P, P, I64, I64, I64, I64, P, I64, I64, I64, I64, P, P, I64, c_int, c_int,
+                                       c_int, P, P, P, P, c_int, c_int, P, P, P, P]),
     "fc3d_points_fwd": (c_int, [P, P, P, P, P, I64, c_int, c_int, c_int, P]),
     "fc3d_points_bwd": (c_int, [P, P, P, P, P, I64, c_int, c_int, c_int, P]),
     "fc3d_reproject_fwd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P]),

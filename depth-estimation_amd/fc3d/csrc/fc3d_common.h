@@ -93,6 +93,26 @@ __device__ __forceinline__ void st_at(T* base, unsigned elem, T v) {
     *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + elem * (unsigned)sizeof(T)) = v;
 }
 
+// A pointer argument of a function that is not inlined arrives as a generic pointer in vector
+// registers: its loads become flat_load (which also wait on the LDS counter) with 64-bit per-lane
+// address arithmetic.  uniform_global() restates what the caller knows -- the pointer is the same
+// in every lane and points to global memory -- so ld_global() is a global_load from a scalar base.
+#define FC3D_GLOBAL __attribute__((address_space(1)))
+template <typename T>
+__device__ __forceinline__ const FC3D_GLOBAL T* uniform_global(const T* p) {
+    const uint64_t a = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    return reinterpret_cast<const FC3D_GLOBAL T*>(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ float ld_global(const FC3D_GLOBAL float* base, unsigned elem) {
+    return *reinterpret_cast<const FC3D_GLOBAL float*>(reinterpret_cast<const FC3D_GLOBAL char*>(base) + elem * 4u);
+}
+__device__ __forceinline__ float2 ld_global(const FC3D_GLOBAL float2* base, unsigned elem) {
+    typedef float f2v __attribute__((ext_vector_type(2)));     // a plain vector: float2's copy constructor takes generic references only
+    const f2v v = *reinterpret_cast<const FC3D_GLOBAL f2v*>(reinterpret_cast<const FC3D_GLOBAL char*>(base) + elem * 8u);
+    return make_float2(v.x, v.y);
+}
+
 template <typename T>
 __device__ __forceinline__ T wave_max(T v) {
 #pragma unroll

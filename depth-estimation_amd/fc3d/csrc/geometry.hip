@@ -106,6 +106,68 @@ __global__ void pose_transforms_kernel(const float* __restrict__ pose, const flo
     }
 }
 
+// invert4 spread over the lanes of one wavefront: lane r*8 + j (upper half: a copy of the lower)
+// holds tableau entry m[r][j].  Every entry sees the operations invert4 applies to it, in the same
+// order, so the rounded inverse is the same; a lane needs one double instead of thirty-two, which
+// lets a streaming kernel invert its sample's pose on the side without giving up resident wavefronts.
+__device__ __forceinline__ double invert4_lanes(const float* __restrict__ a, int lane) {
+    const int l = lane & 31, r = l >> 3, j = l & 7;
+    double m = j < 4 ? (double)a[r * 4 + j] : (j - 4 == r ? 1.0 : 0.0);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int r2 = c + 1; r2 < 4; ++r2) {        // the largest |m[r][c]|, r >= c, ends up in row c (first one on ties)
+            const double pc = __shfl(m, c * 8 + c, 64), pr = __shfl(m, r2 * 8 + c, 64);
+            const int partner = (r == c ? r2 : (r == r2 ? c : r)) * 8 + j;
+            const double other = __shfl(m, partner, 64);
+            if (fabs(pr) > fabs(pc)) m = other;
+        }
+        const double d = 1.0 / __shfl(m, c * 8 + c, 64);
+        if (r == c) m *= d;
+        const double f = __shfl(m, r * 8 + c, 64);
+        const double mc = __shfl(m, c * 8 + j, 64);
+        if (r != c) m -= f * mc;
+    }
+    return m;
+}
+
+// Element (i, j) = lane & 15 of K*A, the 4x4 product as torch's small-matrix loop rounds it
+// (intrinsics_times), with A's element (k, j) supplied by the caller's accessor.
+template <typename Acol>
+__device__ __forceinline__ float intrinsics_times_lane(const float* __restrict__ K, int i, Acol a_kj) {
+    float s = __fmul_rn(K[i * 4 + 0], a_kj(0));
+    s = __fadd_rn(s, __fmul_rn(K[i * 4 + 1], a_kj(1)));
+    s = __fadd_rn(s, __fmul_rn(K[i * 4 + 2], a_kj(2)));
+    s = __fadd_rn(s, __fmul_rn(K[i * 4 + 3], a_kj(3)));
+    return s;
+}
+
+// What pose_transforms_kernel computes for one sample, by one wavefront, on the side of another kernel.
+struct PoseArgs {
+    const float* pose;      // [B][16]
+    const float* K;         // K[b*k_sb + 4*i + j]
+    long k_sb;
+    float* t_fwd;           // [B][16] K*pose
+    float* t_inv;           // [B][16] K*inverse(pose)
+    float* inv;             // [B][16] inverse(pose), may be null
+};
+__device__ __forceinline__ void pose_outputs_wave(const PoseArgs& pa, int b, int lane, float t_fwd_e) {
+    const float* A = pa.pose + (long)b * 16;
+    const float* Kb = pa.K + (long)b * pa.k_sb;
+    const int e = lane & 15, i = e >> 2, j = e & 3;
+    const double m = invert4_lanes(A, lane);
+    float af[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) af[k] = (float)__shfl(m, k * 8 + 4 + j, 64);
+    const float own = (float)__shfl(m, i * 8 + 4 + j, 64);
+    const float ti = intrinsics_times_lane(Kb, i, [&](int k) { return af[k]; });
+    if (lane < 16) {
+        pa.t_fwd[(long)b * 16 + e] = t_fwd_e;
+        pa.t_inv[(long)b * 16 + e] = ti;
+        if (pa.inv) pa.inv[(long)b * 16 + e] = own;
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // projection
 // ---------------------------------------------------------------------------------------
@@ -131,20 +193,45 @@ __device__ __forceinline__ void load_coord(const float* __restrict__ base, long 
 }
 
 // coord_transform; with SPLAT also the 'all' visibility splat of warp_p2c's forward warp.
-template <int LAYOUT, bool FMA, bool SPLAT>
+// With POSE the transform is not read but formed here, T = K*pose (every wavefront for itself: one
+// element per lane, handed round as scalars), and the first wavefront of every sample also leaves
+// K*pose, K*inverse(pose) and inverse(pose) in memory for the kernels behind this one -- what
+// pose_transforms_kernel would do in a launch of its own.
+template <int LAYOUT, bool FMA, bool SPLAT, bool POSE = false>
 __global__ __launch_bounds__(NT) void project_kernel(const float* __restrict__ coord, long sb, long sc, long sh,
                                                      long sw, const float* __restrict__ Tm, int H, int W,
-                                                     float* __restrict__ grid, uint8_t* __restrict__ mask_u8) {
+                                                     float* __restrict__ grid, uint8_t* __restrict__ mask_u8,
+                                                     PoseArgs pa) {
     const int b = blockIdx.y;
     const long HW = (long)H * W;
     const long p0 = lane_first_pixel<false>();
-    const float* T = Tm + (long)b * 16;
     const float* cb = coord + (long)b * sb;
     float c[PPL][4];
 #pragma unroll
     for (int i = 0; i < PPL; ++i) {
         const long p = p0 + 64 * i;
         if (p < HW) load_coord<LAYOUT>(cb, sc, sh, sw, p, W, c[i]);
+    }
+    // after the coordinate loads were issued: the few words of K and pose arrive under their latency
+    float T[16];
+    if (POSE) {
+        // two loads per lane (element lane & 15 of either matrix), the row of K and the column of
+        // pose a lane needs then come from its neighbours
+        const int lane = threadIdx.x & 63, e = lane & 15, i = e >> 2, j = e & 3;
+        const float kv = pa.K[(long)b * pa.k_sb + e], av = pa.pose[(long)b * 16 + e];
+        float kr[4], ac[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            kr[k] = __shfl(kv, i * 4 + k, 64);
+            ac[k] = __shfl(av, k * 4 + j, 64);
+        }
+        const float te = intrinsics_times_lane(kr, 0, [&](int k) { return ac[k]; });
+#pragma unroll
+        for (int k = 0; k < 16; ++k) T[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(te), k));
+        if (blockIdx.x == 0 && threadIdx.x < 64) pose_outputs_wave(pa, b, lane, te);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) T[k] = Tm[(long)b * 16 + k];
     }
     float2* go = reinterpret_cast<float2*>(grid) + (long)b * HW;
     uint8_t* m = SPLAT ? mask_u8 + (long)b * HW : nullptr;
@@ -169,7 +256,7 @@ template <int LAYOUT, bool FMA>
 __global__ __launch_bounds__(NT) void warp_sample_kernel(const float* __restrict__ coord, long sb, long sc, long sh,
                                                          long sw, const float* __restrict__ Tm,
                                                          const float* __restrict__ Ip,
-                                                         const uint8_t* __restrict__ mask_u8, int H, int W,
+                                                         uint8_t* mask_u8, int rezero, int H, int W,
                                                          float* __restrict__ grid, float* __restrict__ out,
                                                          void* __restrict__ tap_index, int B) {
     const int b = blockIdx.y;
@@ -178,7 +265,7 @@ __global__ __launch_bounds__(NT) void warp_sample_kernel(const float* __restrict
     const float* T = Tm + (long)b * 16;
     const float* cb = coord + (long)b * sb;
     const float* img = Ip + (long)b * HW;
-    const uint8_t* mk = mask_u8 + (long)b * HW;
+    uint8_t* mk = mask_u8 + (long)b * HW;
     float c[PPL][4];
     float mv[PPL];
 #pragma unroll
@@ -211,6 +298,20 @@ __global__ __launch_bounds__(NT) void warp_sample_kernel(const float* __restrict
         if (p < HW) {
             go[p] = make_float2(gx[i], gy[i]);
             oo[p] = blend(t[i], i00[i], i01[i], i10[i], i11[i]) * mv[i];
+        }
+    }
+    if (rezero) {
+        // The mask leaves the launch cleared for its next use.  A wavefront's 64*PPL bytes are read by
+        // its own lanes only, and those loads have returned (their values went into the stores above),
+        // so a few lanes can clear the run with 16-byte stores; byte stores where the run is ragged.
+        const long run0 = p0 - (threadIdx.x & 63);
+        const int lane = threadIdx.x & 63;
+        if (rezero == 2 && run0 + 64 * PPL <= HW) {
+            if (lane < 64 * PPL / 16) *reinterpret_cast<uint4*>(mk + run0 + lane * 16) = make_uint4(0u, 0u, 0u, 0u);
+        } else {
+#pragma unroll
+            for (int i = 0; i < PPL; ++i)
+                if (p0 + 64 * i < HW) mk[p0 + 64 * i] = 0;
         }
     }
     if (tap_index) {   // for the gradient w.r.t. Ip: where this workgroup's pixels sampled the pattern
@@ -542,6 +643,7 @@ __device__ __forceinline__ int list_append(L list, int n, bool hit, V value, int
     return n + __popcll(bal);
 }
 
+constexpr int G_WIN = GWR * GWS;                 // window cells
 // window_add4 with the election slots shared by all cells that agree in the low bits of their
 // index: two lanes with different cells may now meet in a slot, in which case one of them simply
 // waits a turn.
@@ -578,6 +680,8 @@ __device__ __noinline__ void gather_drain(const float2* __restrict__ gb, const f
                                           GatherTile tl) {
     constexpr int STEP = 64 / SEG;
     const int lane = threadIdx.x & 63;
+    const auto gbu = uniform_global(gb);
+    const auto vbu = uniform_global(vb);
     for (int e0 = 0; e0 < n; e0 += STEP * G_DEPTH) {
         GatherSample sm[G_DEPTH];
 #pragma unroll
@@ -589,8 +693,8 @@ __device__ __noinline__ void gather_drain(const float2* __restrict__ gb, const f
                 const unsigned p = (unsigned)seg * SEG + (lane & 15);
                 sm[d].live = (e + (lane >> 4) < n) && ((bits >> (lane & 15)) & 1);   // a live pixel lies inside the target image
                 const unsigned q = min(p, HWt - 1u);
-                sm[d].g = ld_at(gb, q);
-                sm[d].v = ld_at(vb, q);
+                sm[d].g = ld_global(gbu, q);
+                sm[d].v = ld_global(vbu, q);
             }
         }
 #pragma unroll
@@ -613,10 +717,13 @@ __device__ __noinline__ void gather_drain(const float2* __restrict__ gb, const f
     }
 }
 
+#ifdef FC3D_GATHER_WAVES
+__attribute__((amdgpu_waves_per_eu(FC3D_GATHER_WAVES, FC3D_GATHER_WAVES)))
+#endif
 __global__ __launch_bounds__(NT) void bilinear_bwd_img_gather_kernel(
     const float* __restrict__ g_out, const float* __restrict__ grid, void* __restrict__ tap_index, int B, int groups,
     int Hs, int Ws, unsigned HWt, float* __restrict__ g_img) {
-    __shared__ __align__(16) float s_win[NT / 64][GWR * GWS];
+    __shared__ __align__(16) float s_win[NT / 64][G_WIN];
     __shared__ uint8_t s_own[NT / 64][G_OWN];
     __shared__ int s_ghit[NT / 64][G_GROUPS / (NT / 64)];   // groups that meet the workgroup's row of tiles, per scanning wavefront
     __shared__ int s_ng[NT / 64];
@@ -1253,7 +1360,8 @@ extern "C" int fc3d_project_fwd(void* stream, const float* coord, int64_t sb, in
     dim3 g(cdiv((long)H * W, PX_PER_BLOCK), B), blk(NT);
     hipStream_t s = (hipStream_t)stream;
     uint8_t* nomask = nullptr;
-#define ARGS coord, (long)sb, (long)sc, (long)sh, (long)sw, T, H, W, grid_out, nomask
+    const PoseArgs nopose = {};
+#define ARGS coord, (long)sb, (long)sc, (long)sh, (long)sw, T, H, W, grid_out, nomask, nopose
     FC3D_DISPATCH_LAYOUT("project_fwd", project_kernel, layout, fma, false);
 #undef ARGS
     FC3D_LAUNCH_CHECK();
@@ -1418,11 +1526,14 @@ extern "C" int fc3d_visible_mask(void* stream, const float* grid, int B, int H, 
     return FC3D_OK;
 }
 
-extern "C" int fc3d_warp_p2c_fwd(void* stream, const float* Ip, const float* coord_p, int64_t p_sb, int64_t p_sc,
-                                 int64_t p_sh, int64_t p_sw, const float* coord_c, int64_t c_sb, int64_t c_sc,
-                                 int64_t c_sh, int64_t c_sw, const float* T_p2c, const float* T_c2p, int B, int H,
-                                 int W, float* Ic_masked, float* grid_p2c, float* grid_c2p, uint8_t* mask_u8,
-                                 int mask_is_clear, void* tap_index) {
+// warp_p2c forward.  pose == NULL: the transforms T_p2c / T_c2p are inputs.  Otherwise they are
+// outputs: the projection kernel forms them from pose and K (no separate pose_transforms launch).
+static int warp_p2c_launch(void* stream, const float* Ip, const float* coord_p, int64_t p_sb, int64_t p_sc,
+                           int64_t p_sh, int64_t p_sw, const float* coord_c, int64_t c_sb, int64_t c_sc,
+                           int64_t c_sh, int64_t c_sw, float* T_p2c, float* T_c2p, const float* pose,
+                           const float* K, int64_t k_sb, float* inv_out, int B, int H, int W, float* Ic_masked,
+                           float* grid_p2c, float* grid_c2p, uint8_t* mask_u8, int mask_is_clear, int mask_rezero,
+                           void* tap_index) {
     if (!Ip || !coord_p || !coord_c || !T_p2c || !T_c2p || !Ic_masked || !grid_p2c || !grid_c2p || !mask_u8)
         return FC3D_EINVAL;
     if (int e = check_img(B, H, W)) return e;
@@ -1439,19 +1550,45 @@ extern "C" int fc3d_warp_p2c_fwd(void* stream, const float* Ip, const float* coo
     }
     {
         const int layout = pick_layout(coord_p, p_sc, p_sh, p_sw, W);
-#define ARGS coord_p, (long)p_sb, (long)p_sc, (long)p_sh, (long)p_sw, T_p2c, H, W, grid_p2c, mask_u8
-        FC3D_DISPATCH_LAYOUT("warp_project_splat", project_kernel, layout, fma, true);
+        const PoseArgs pa = {pose, K, (long)k_sb, T_p2c, T_c2p, inv_out};
+#define ARGS coord_p, (long)p_sb, (long)p_sc, (long)p_sh, (long)p_sw, (const float*)T_p2c, H, W, grid_p2c, mask_u8, pa
+        if (pose) FC3D_DISPATCH_LAYOUT("warp_project_splat", project_kernel, layout, fma, true, true);
+        else FC3D_DISPATCH_LAYOUT("warp_project_splat", project_kernel, layout, fma, true);
 #undef ARGS
         FC3D_LAUNCH_CHECK();
     }
     {
         const int layout = pick_layout(coord_c, c_sc, c_sh, c_sw, W);
-#define ARGS coord_c, (long)c_sb, (long)c_sc, (long)c_sh, (long)c_sw, T_c2p, Ip, (const uint8_t*)mask_u8, H, W, grid_c2p, Ic_masked, tap_index, B
+        // 2: runs of 64*PPL bytes start 16-byte aligned in every image, so they can be cleared with 16-byte stores
+        const int rezero = !mask_rezero ? 0 : ((aligned16(mask_u8) && ((long)H * W) % 16 == 0) ? 2 : 1);
+#define ARGS coord_c, (long)c_sb, (long)c_sc, (long)c_sh, (long)c_sw, (const float*)T_c2p, Ip, mask_u8, rezero, H, W, grid_c2p, Ic_masked, tap_index, B
         FC3D_DISPATCH_LAYOUT("warp_sample", warp_sample_kernel, layout, fma);
 #undef ARGS
         FC3D_LAUNCH_CHECK();
     }
     return FC3D_OK;
+}
+
+extern "C" int fc3d_warp_p2c_fwd(void* stream, const float* Ip, const float* coord_p, int64_t p_sb, int64_t p_sc,
+                                 int64_t p_sh, int64_t p_sw, const float* coord_c, int64_t c_sb, int64_t c_sc,
+                                 int64_t c_sh, int64_t c_sw, const float* T_p2c, const float* T_c2p, int B, int H,
+                                 int W, float* Ic_masked, float* grid_p2c, float* grid_c2p, uint8_t* mask_u8,
+                                 int mask_is_clear, void* tap_index) {
+    return warp_p2c_launch(stream, Ip, coord_p, p_sb, p_sc, p_sh, p_sw, coord_c, c_sb, c_sc, c_sh, c_sw,
+                           const_cast<float*>(T_p2c), const_cast<float*>(T_c2p), nullptr, nullptr, 0, nullptr, B, H, W,
+                           Ic_masked, grid_p2c, grid_c2p, mask_u8, mask_is_clear, 0, tap_index);
+}
+
+extern "C" int fc3d_warp_p2c_pose_fwd(void* stream, const float* Ip, const float* coord_p, int64_t p_sb, int64_t p_sc,
+                                      int64_t p_sh, int64_t p_sw, const float* coord_c, int64_t c_sb, int64_t c_sc,
+                                      int64_t c_sh, int64_t c_sw, const float* pose, const float* K, int64_t k_sb,
+                                      int B, int H, int W, float* Ic_masked, float* grid_p2c, float* grid_c2p,
+                                      uint8_t* mask_u8, int mask_is_clear, int mask_rezero, void* tap_index,
+                                      float* T_p2c_out, float* T_c2p_out, float* inv_out) {
+    if (!pose || !K) return FC3D_EINVAL;
+    return warp_p2c_launch(stream, Ip, coord_p, p_sb, p_sc, p_sh, p_sw, coord_c, c_sb, c_sc, c_sh, c_sw, T_p2c_out,
+                           T_c2p_out, pose, K, k_sb, inv_out, B, H, W, Ic_masked, grid_p2c, grid_c2p, mask_u8,
+                           mask_is_clear, mask_rezero, tap_index);
 }
 
 extern "C" int fc3d_points_fwd(void* stream, const float* z, const float* ray_x, const float* ray_y,

@@ -57,7 +57,9 @@ class GraphedImageFormation:
         g = torch.cuda.CUDAGraph()
         # thread_local: calls made meanwhile by other threads of the process (e.g. the collective
         # library's watchdog) do not invalidate the capture
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        # captured on the stream the warm-up ran on: per-stream state the operators keep (the
+        # self-clearing visibility mask of warp_p2c) is then in place and becomes part of the graph
+        with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
             outs = self._step()
         self.graph = g
         self.outputs = tuple(o.detach() for o in outs)

@@ -394,6 +394,101 @@ class WarpP2CFn(torch.autograd.Function):
         return gi, None, None, None, None, None
 
 
+# Visibility-mask buffers that hold zeros between calls: fc3d_warp_p2c_pose_fwd's sampling kernel
+# stores zeros back into the mask it has just consumed, so a buffer is cleared once, when it is
+# made, and never again.  One buffer per (device, stream, shape): calls on one stream are ordered.
+# A buffer that a stream capture has used stays for good (the graph replays write to its address);
+# a capture only uses a buffer that exists already, i.e. one made by eager calls on the same stream.
+_zero_masks: dict = {}
+_zero_masks_pinned: set = set()
+
+
+def _pooled_zero_mask(B, H, W, dev, stream, capturing):
+    key = (dev.index, stream, B, H, W)
+    m = _zero_masks.get(key)
+    if m is None:
+        if capturing:
+            return key, None
+        for k in [k for k in _zero_masks if k not in _zero_masks_pinned][:max(0, len(_zero_masks) - 7)]:
+            del _zero_masks[k]
+        m = torch.zeros((B, H, W), dtype=torch.uint8, device=dev)
+        _zero_masks[key] = m
+    if capturing:
+        _zero_masks_pinned.add(key)
+    return key, m
+
+
+def _intrinsics_args(K, B):
+    """(dense K, element stride between samples) for a [4,4] or [B,4,4] / [1,4,4] intrinsic matrix."""
+    K = _dense(K)
+    if K.dim() == 3:
+        if K.shape[0] not in (1, B) or tuple(K.shape[1:]) != (4, 4):
+            raise RuntimeError(f"intrinsics must be [B,4,4], got {tuple(K.shape)}")
+        return K, (16 if K.shape[0] == B and B > 1 else 0)
+    if tuple(K.shape) != (4, 4):
+        raise RuntimeError(f"intrinsics must be [4,4] or [B,4,4], got {tuple(K.shape)}")
+    return K, 0
+
+
+class WarpP2CPoseFn(torch.autograd.Function):
+    """warp_p2c from the pose and the intrinsic matrix, gradient w.r.t. Ip only (geometry_pytorch.py:255-281):
+    two launches -- the projection kernel forms K*pose and K*inverse(pose) on the side.  With the
+    ordered image gradient the visibility mask is dead once the sampling kernel has read it; the
+    kernel then stores zeros back and the buffer is reused by the next call without a clear.
+    Returns (Ic_masked, grid_p2c, grid_c2p)."""
+
+    @staticmethod
+    def forward(ctx, Ip, coord_p, coord_c, pose, K):
+        dev = _need_gpu(Ip, coord_p, coord_c, pose, K)
+        coord_p, sp = _coord_args(coord_p)
+        coord_c, sc = _coord_args(coord_c)
+        B, _, H, W = coord_p.shape
+        if tuple(coord_c.shape) != (B, 4, H, W) or tuple(Ip.shape) != (B, H, W, 1):
+            raise RuntimeError(f"warp_p2c: Ip {tuple(Ip.shape)}, coord_p {tuple(coord_p.shape)}, "
+                               f"coord_c {tuple(coord_c.shape)}")
+        if tuple(pose.shape) != (B, 4, 4):
+            raise RuntimeError(f"pose must be [{B},4,4], got {tuple(pose.shape)}")
+        ip, po = _dense(Ip), _dense(pose)
+        K, k_sb = _intrinsics_args(K, B)
+        Ic = torch.empty((B, H, W, 1), dtype=torch.float32, device=dev)
+        gp2c = torch.empty((B, H, W, 2), dtype=torch.float32, device=dev)
+        gc2p = torch.empty((B, H, W, 2), dtype=torch.float32, device=dev)
+        tt = torch.empty((2, B, 4, 4), dtype=torch.float32, device=dev)
+        want_grad = ctx.needs_input_grad[0]
+        ordered = _img_grad_ordered()
+        index = _tap_index_buffer(B, H, W, H, W, dev) if (want_grad and ordered) else None
+        with _on_device(dev):
+            s = _stream()
+            # the mask outlives the call only where the atomic form of the gradient reads it again
+            key = mask = None
+            if not (want_grad and index is None):
+                key, mask = _pooled_zero_mask(B, H, W, dev, s, torch.cuda.is_current_stream_capturing())
+            pooled = mask is not None
+            if not pooled:
+                mask = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+            status = _lib.fc3d_warp_p2c_pose_fwd(
+                s, ip.data_ptr(), coord_p.data_ptr(), sp[0], sp[1], sp[2], sp[3], coord_c.data_ptr(), sc[0], sc[1],
+                sc[2], sc[3], po.data_ptr(), K.data_ptr(), k_sb, B, H, W, Ic.data_ptr(), gp2c.data_ptr(),
+                gc2p.data_ptr(), mask.data_ptr(), int(pooled), int(pooled),
+                index.data_ptr() if index is not None else None, tt[0].data_ptr(), tt[1].data_ptr(), None)
+            if status != 0 and pooled:
+                _zero_masks.pop(key, None)        # its contents are unknown now
+            _check(status, "fc3d_warp_p2c_pose_fwd")
+        ctx.save_for_backward(gc2p, None if pooled else mask, index)
+        ctx.mark_non_differentiable(gp2c, gc2p)
+        ctx.set_materialize_grads(False)
+        return Ic, gp2c, gc2p
+
+    @staticmethod
+    def backward(ctx, g_Ic, _g1, _g2):
+        if g_Ic is None:
+            return None, None, None, None, None
+        gc2p, mask, index = ctx.saved_tensors
+        B, H, W, _ = gc2p.shape
+        gi = _bilinear_bwd_img(_dense(g_Ic), gc2p, mask, B, H, W, 1, H, W, index=index)
+        return gi, None, None, None, None
+
+
 class PointsFn(torch.autograd.Function):
     """points_in_camera_coords; geometry_pytorch.py:44-65.  Returns [B,H,W,4].
     Differentiable in z_map only: the rays are constants of the camera in the reference

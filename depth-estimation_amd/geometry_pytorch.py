@@ -206,12 +206,8 @@ def _warp_p2c(Ip, coord_p, coord_c, pose_p2c, K):
         return Ic * _ops.visible_mask(grid_p2c, 0), grid_p2c, grid_c2p
     if K is None:
         K = _intrinsics_for(coord_p.shape[0], coord_p.device)
-    # the launch that forms the two transforms also clears the visibility mask for the splat
-    B, _, H, W = coord_p.shape
-    mask = torch.empty((B, H, W), dtype=torch.uint8, device=coord_p.device)
-    T_p2c, T_c2p, _ = _ops.pose_transforms(pose_p2c, K, want_fwd=True, want_inv=True, clear=mask)
-    Ic, grid_p2c, grid_c2p, _mask = _ops.WarpP2CFn.apply(Ip, coord_p, coord_c, T_p2c, T_c2p, mask)
-    return Ic, grid_p2c, grid_c2p
+    # two launches: the projection kernel forms K*pose and K*inverse(pose) itself
+    return _ops.WarpP2CPoseFn.apply(Ip, coord_p, coord_c, pose_p2c, K)
 
 
 def zp_cView_to_zc(zp_cView, pose_p2c, xy):

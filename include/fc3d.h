@@ -197,6 +197,24 @@ int fc3d_warp_p2c_fwd(void *stream, const float *Ip,
                       float *Ic_masked, float *grid_p2c, float *grid_c2p, uint8_t *mask_u8,
                       int mask_is_clear, void *tap_index);
 
+/* The same forward (geometry_pytorch.py:255-281, with :271-272 and :103-104 inside) straight from
+ * pose [B][16] and the intrinsics K (read at K[b*k_sb + 4*i + j] as in fc3d_pose_transforms): the
+ * projection kernel forms K*pose itself and its first wavefront per sample leaves K*pose,
+ * K*inverse(pose) and inverse(pose) in T_p2c_out, T_c2p_out [B][16] (both required; T_c2p_out
+ * feeds the sampling kernel) and inv_out [B][16] (may be NULL) -- the values fc3d_pose_transforms
+ * gives, without its launch.  mask_rezero != 0: the sampling kernel, the last reader of the
+ * visibility mask, stores zeros back, so that the caller can hand the same buffer to its next
+ * call with mask_is_clear != 0 and never clears it again (calls that share the buffer must be
+ * ordered on one stream; the mask is not available afterwards, which only the atomic form of the
+ * image gradient needs).                                                                        */
+int fc3d_warp_p2c_pose_fwd(void *stream, const float *Ip,
+                           const float *coord_p, int64_t p_sb, int64_t p_sc, int64_t p_sh, int64_t p_sw,
+                           const float *coord_c, int64_t c_sb, int64_t c_sc, int64_t c_sh, int64_t c_sw,
+                           const float *pose, const float *K, int64_t k_sb, int B, int H, int W,
+                           float *Ic_masked, float *grid_p2c, float *grid_c2p, uint8_t *mask_u8,
+                           int mask_is_clear, int mask_rezero, void *tap_index,
+                           float *T_p2c_out, float *T_c2p_out, float *inv_out);
+
 /* points_in_camera_coords, geometry_pytorch.py:44-65: out [B][H][W][4] =
  * (z*rx, z*ry, z*rz, 1).  Rays either separable (ray_x[W], ray_y[H], rz = 1:
  * the table pixel_to_ray_array :30-41 produces) or a dense table with batch

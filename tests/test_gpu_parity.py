@@ -438,6 +438,55 @@ def test_warp_small(mods, golden, monkeypatch):
     assert rel_err(ti.cpu().numpy(), g["T_c2p"]) < 1e-6
 
 
+def test_warp_pose_in_kernel_matches_separate_transforms(mods, golden, monkeypatch):
+    """warp_p2c's default path forms K*pose and K*inverse(pose) inside the projection kernel and lets the
+    sampling kernel hand the visibility mask back cleared.  Bit for bit what pose_transforms +
+    the transform-fed warp give, also on the second and third call (different poses and depths: a
+    mask that was not cleared would show), with and without the tap index, and the matrices it
+    leaves in memory are pose_transforms' own."""
+    g = golden("g6_warp_small")
+    G, ops, synth = mods["G"], mods["ops"], mods["synth"]
+    monkeypatch.setattr(G, "get_intrinsic", patched_K(float(g["cx"]), float(g["cy"])))
+    H, W = g["z_p"].shape[1:3]
+    rays = G.pixel_to_ray_array(W, H)
+    B = g["z_p"].shape[0]
+    K = G.get_intrinsic(B)
+    for rep, (seed, Ksel) in enumerate(((11, K), (12, K[0]), (13, K[:1]), (11, K))):
+        sc = synth.make_scene(B, H, W, seed=seed, pose_scale=4.0 if rep == 1 else 1.0)
+        coord_p = G.points_in_camera_coords(dev(sc["z_p"]), rays).permute(0, 3, 1, 2)
+        coord_c = G.points_in_camera_coords(dev(sc["z_c"]), rays).permute(0, 3, 1, 2)
+        pose = dev(sc["pose_p2c"])
+        ip = dev(g["Ip"]).requires_grad_(rep != 2)
+        Ic, gp2c, gc2p = ops.WarpP2CPoseFn.apply(ip, coord_p, coord_c, pose, Ksel)
+        tf, ti, _ = ops.pose_transforms(pose, K, want_fwd=True, want_inv=True)
+        ip2 = dev(g["Ip"]).requires_grad_(rep != 2)
+        Ic2, gp2, gc2, mask2 = ops.WarpP2CFn.apply(ip2, coord_p, coord_c, tf, ti, None)
+        assert torch.equal(gp2c, gp2) and torch.equal(gc2p, gc2) and torch.equal(Ic, Ic2), rep
+        if rep != 2:
+            Ic.backward(dev(g["g"]))
+            Ic2.backward(dev(g["g"]))
+            assert torch.equal(ip.grad, ip2.grad), rep
+    for m in ops._zero_masks.values():
+        assert int(m.count_nonzero()) == 0          # every pooled mask is back to zeros
+    # the matrices written on the side
+    lib = ops._lib
+    sc = synth.make_scene(B, H, W, seed=21)
+    coord_p = G.points_in_camera_coords(dev(sc["z_p"]), rays).permute(0, 3, 1, 2).contiguous()
+    pose = dev(sc["pose_p2c"])
+    out = [torch.empty((B, H, W, c), device="cuda") for c in (1, 2, 2)]
+    mats = torch.full((3, B, 4, 4), float("nan"), device="cuda")
+    mask = torch.zeros((B, H, W), dtype=torch.uint8, device="cuda")
+    st = coord_p.stride()
+    ops._check(lib.fc3d_warp_p2c_pose_fwd(ops._stream(), dev(g["Ip"]).data_ptr(), coord_p.data_ptr(), *st,
+                                          coord_p.data_ptr(), *st, pose.data_ptr(), K.data_ptr(), 16, B, H, W,
+                                          out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), mask.data_ptr(),
+                                          1, 0, None, mats[0].data_ptr(), mats[1].data_ptr(), mats[2].data_ptr()),
+               "fc3d_warp_p2c_pose_fwd")
+    tf, ti, a = ops.pose_transforms(pose, K, True, True, True)
+    assert torch.equal(mats[0], tf) and torch.equal(mats[1], ti) and torch.equal(mats[2], a)
+    assert int(mask.count_nonzero()) > 0            # mask_rezero = 0: the mask stays available
+
+
 def test_warp_differentiable_geometry_path(mods, golden, monkeypatch):
     """warp_p2c with coords that require grad takes the composed-operator path; same numbers."""
     g = golden("g6_warp_small")
