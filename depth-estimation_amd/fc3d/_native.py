@@ -34,6 +34,10 @@ SIGNATURES = {
                                              POINTER(c_int)]),
     "fc3d_code_pattern_norm": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P]),
     "fc3d_code_pattern_bwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "fc3d_code_pattern_bwd_dot_supported": (c_int, [c_int, c_int, c_int]),
+    "fc3d_code_pattern_bwd_dot": (c_int, [P, P, P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "fc3d_bilinear_bwd_img_dot_count": (c_int, [c_int, c_int]),
+    "fc3d_bilinear_bwd_img_dot": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P]),
     "fc3d_pose_transforms": (c_int, [P, P, P, I64, c_int, P, P, P, P, c_size_t]),
     "fc3d_project_fwd": (c_int, [P, P, I64, I64, I64, I64, P, c_int, c_int, c_int, P]),
     "fc3d_project_bwd": (c_int, [P, P, P, I64, I64, I64, I64, P, c_int, c_int, c_int, P]),

@@ -722,7 +722,8 @@ __attribute__((amdgpu_waves_per_eu(FC3D_GATHER_WAVES, FC3D_GATHER_WAVES)))
 #endif
 __global__ __launch_bounds__(NT) void bilinear_bwd_img_gather_kernel(
     const float* __restrict__ g_out, const float* __restrict__ grid, void* __restrict__ tap_index, int B, int groups,
-    int Hs, int Ws, unsigned HWt, float* __restrict__ g_img) {
+    int Hs, int Ws, unsigned HWt, float* __restrict__ g_img, const float* __restrict__ img,
+    float* __restrict__ dot_partial) {
     __shared__ __align__(16) float s_win[NT / 64][G_WIN];
     __shared__ uint8_t s_own[NT / 64][G_OWN];
     __shared__ int s_ghit[NT / 64][G_GROUPS / (NT / 64)];   // groups that meet the workgroup's row of tiles, per scanning wavefront
@@ -839,11 +840,29 @@ __global__ __launch_bounds__(NT) void bilinear_bwd_img_gather_kernel(
         }
         __syncthreads();                              // s_ghit is rewritten by the next round
     }
-    if (!tile_live) return;
+    // dot_partial (with img, the image that was sampled): one value per tile, the sum over the tile of
+    // (gradient just formed) * img -- what a normalisation of img by one of its own statistics needs in
+    // its backward pass; tile t of image b at dot_partial[b * tiles + t], tiles = all wavefronts of a grid z-slice
+    const long dslot = ((long)b * gridDim.y + blockIdx.y) * (gridDim.x * (NT / 64)) + blockIdx.x * (NT / 64) + wv;
+    if (!tile_live) {
+        if (dot_partial && lane == 0) dot_partial[dslot] = 0.0f;
+        return;
+    }
 
     // the tile goes out with plain stores: four rows of sixteen 16-byte groups per step
     float* o = g_img + (long)b * Hs * Ws;
-    const bool vec = (Ws % 4 == 0) && (reinterpret_cast<uintptr_t>(g_img) % 16 == 0);
+    const float* im = img + (long)b * Hs * Ws;
+    const bool vec = (Ws % 4 == 0) && (reinterpret_cast<uintptr_t>(g_img) % 16 == 0) &&
+                     (!dot_partial || reinterpret_cast<uintptr_t>(img) % 16 == 0);
+    float dot = 0.0f;
+    float4 iv[(GY + 3) / 4];
+    if (dot_partial && vec) {      // the image tile's loads go first: they are under way while the window is read back
+#pragma unroll
+        for (int r0 = 0; r0 < GY; r0 += 4) {
+            const int r = min(r0 + (lane >> 4), GY - 1), x = min(sx0 + 4 * (lane & 15), Ws - 4), y = min(sy0 + r, Hs - 1);
+            iv[r0 / 4] = ld_at(reinterpret_cast<const float4*>(im), ((unsigned)y * (unsigned)Ws + (unsigned)x) >> 2);
+        }
+    }
 #pragma unroll
     for (int r0 = 0; r0 < GY; r0 += 4) {
         const int r = r0 + (lane >> 4), x = sx0 + 4 * (lane & 15), y = sy0 + r;
@@ -851,13 +870,25 @@ __global__ __launch_bounds__(NT) void bilinear_bwd_img_gather_kernel(
             const float4 v = *reinterpret_cast<const float4*>(&s_win[wv][(r + 1) * GWS + 4 + 4 * (lane & 15)]);
             if (vec) {
                 st_at(reinterpret_cast<float4*>(o), ((unsigned)y * (unsigned)Ws + (unsigned)x) >> 2, v);
+                if (dot_partial) {
+                    const float4 w = iv[r0 / 4];
+                    dot = fmaf(v.x, w.x, dot); dot = fmaf(v.y, w.y, dot);
+                    dot = fmaf(v.z, w.z, dot); dot = fmaf(v.w, w.w, dot);
+                }
             } else {
                 const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    if (x + k < Ws) o[(long)y * Ws + x + k] = vv[k];
+                    if (x + k < Ws) {
+                        o[(long)y * Ws + x + k] = vv[k];
+                        if (dot_partial) dot = fmaf(vv[k], im[(long)y * Ws + x + k], dot);
+                    }
             }
         }
+    }
+    if (dot_partial) {
+        dot = wave_sum(dot);
+        if (lane == 0) dot_partial[dslot] = dot;
     }
 }
 
@@ -1502,7 +1533,27 @@ extern "C" int fc3d_bilinear_bwd_img(void* stream, const float* g_out, const flo
     }
     FC3D_LAUNCH("bilinear_bwd_img_gather", bilinear_bwd_img_gather_kernel, dim3(cdiv(Ws, (NT / 64) * GX), cdiv(Hs, GY), B),
                 dim3(NT), 0, s, g_out, grid, index, B, (int)tap_index_groups(Ht, Wt), Hs, Ws,
-                (unsigned)((long)Ht * Wt), g_img);
+                (unsigned)((long)Ht * Wt), g_img, (const float*)nullptr, (float*)nullptr);
+    return FC3D_OK;
+}
+
+extern "C" int fc3d_bilinear_bwd_img_dot_count(int Hs, int Ws) {
+    if (Hs <= 0 || Ws <= 0) return 0;
+    return cdiv(Ws, (NT / 64) * GX) * (NT / 64) * cdiv(Hs, GY);
+}
+
+extern "C" int fc3d_bilinear_bwd_img_dot(void* stream, const float* g_out, const float* grid, int B, int Hs, int Ws,
+                                         int Ht, int Wt, void* index, const float* img, float* g_img,
+                                         float* dot_partial) {
+    if (!g_out || !grid || !g_img || !index || !img || !dot_partial) return FC3D_EINVAL;
+    if (int e = check_img(B, Hs, Ws)) return e;
+    if (int e = check_img(B, Ht, Wt)) return e;
+    if (!gather_fits(Hs, Ws, Ht, Wt)) return FC3D_ERANGE;
+    if ((reinterpret_cast<uintptr_t>(grid) & 7u) || (reinterpret_cast<uintptr_t>(index) & 7u)) return FC3D_EALIGN;
+    if (!aligned4(img) || !aligned4(g_img) || !aligned4(dot_partial)) return FC3D_EALIGN;
+    FC3D_LAUNCH("bilinear_bwd_img_gather", bilinear_bwd_img_gather_kernel, dim3(cdiv(Ws, (NT / 64) * GX), cdiv(Hs, GY), B),
+                dim3(NT), 0, (hipStream_t)stream, g_out, grid, index, B, (int)tap_index_groups(Ht, Wt), Hs, Ws,
+                (unsigned)((long)Ht * Wt), g_img, img, dot_partial);
     return FC3D_OK;
 }
 

@@ -508,11 +508,18 @@ __device__ __forceinline__ void stage_psf_stack(float* __restrict__ wts, const f
 // also sums g*out over the pixels it owns into one partial per wavefront, and a follow-up kernel
 // (one workgroup per image) adds the partials in a fixed order and applies the K x K footprint
 // of that single pixel.  This saves a separate pass over g and out.
-template <int K, int R>
+//
+// DOT: sum(g*out) is known already -- the caller hands over partial sums of it (dot_partial, ndot per
+// image; the sampler's backward forms them while it writes g).  Then `out` is not read at all and the
+// maximum's share goes in at the source: the pixel that holds the maximum scatters (g - S)/den
+// instead of g/den, so there is no follow-up kernel either.  Only a wavefront whose source rows and
+// columns contain that pixel adds up the partials (fixed order).
+template <int K, int R, bool DOT = false>
 __global__ __launch_bounds__(NT) void code_pattern_bwd_roll_kernel(
     const float* __restrict__ g, const float* __restrict__ out, const uint8_t* __restrict__ layer_u8,
     const float* __restrict__ max_in, const float* __restrict__ psf, int H, int W, int L, int nstrips,
-    float* __restrict__ partial, float* __restrict__ g_pat0) {
+    float* __restrict__ partial, float* __restrict__ g_pat0, const int* __restrict__ argmax_in,
+    const float* __restrict__ dot_partial, int ndot) {
     constexpr int PAD = Roll<K>::PAD, SW = Roll<K>::SW, KKP = Roll<K>::KKP;
     constexpr int NR = R + K - 1;                 // source rows a strip reads
     extern __shared__ float smem[];               // [L][KKP]
@@ -545,22 +552,41 @@ __global__ __launch_bounds__(NT) void code_pattern_bwd_roll_kernel(
         gv[r] = ld_at(gi, q);
         lv[r] = ld_at(li, q);
     }
+    if (!DOT) {
 #pragma unroll
-    for (int o = 0; o < R; ++o) ov[o] = ld_at(oi, (unsigned)(min(y0 + o, H - 1) * W + xc));
+        for (int o = 0; o < R; ++o) ov[o] = ld_at(oi, (unsigned)(min(y0 + o, H - 1) * W + xc));
+    }
     const float den = max_in[b] + 1e-10f;
     const float rden = 1.0f / den;
+    // DOT: the maximum's pixel (py, px); sfix = S in the lane that holds column px of a wavefront
+    // whose source rows contain py, zero everywhere else
+    int py = -1;
+    float sfix = 0.0f;
+    if (DOT) {
+        const int am = argmax_in[b];
+        py = am / W;
+        const int px = am - py * W;
+        if (y0 < H && py >= y0 - PAD && py < y0 - PAD + NR && px >= xs - PAD && px < xs - PAD + 64) {   // the same for all lanes
+            float sp = 0.0f;
+            for (int i = lane; i < ndot; i += 64) sp += dot_partial[(long)b * ndot + i];
+            sp = wave_sum(sp);
+            sfix = (colok && x == px) ? sp : 0.0f;
+        }
+    }
     stage_psf_stack<K>(smem, psf, L);
     __syncthreads();
     if (y0 >= H) {
-        if (lane == 0) partial[pidx] = 0.0f;
+        if (!DOT && lane == 0) partial[pidx] = 0.0f;
         return;
     }
     const bool mine = lane >= PAD && lane < 64 - PAD && x < W;   // columns this lane writes
-    float sgo = 0.0f;
+    if (!DOT) {
+        float sgo = 0.0f;
 #pragma unroll
-    for (int o = 0; o < R; ++o) sgo = fmaf((mine && y0 + o < H) ? gv[o + PAD] : 0.0f, ov[o], sgo);
-    sgo = wave_sum(sgo);
-    if (lane == 0) partial[pidx] = sgo;
+        for (int o = 0; o < R; ++o) sgo = fmaf((mine && y0 + o < H) ? gv[o + PAD] : 0.0f, ov[o], sgo);
+        sgo = wave_sum(sgo);
+        if (lane == 0) partial[pidx] = sgo;
+    }
 
     float w[KKP];
     int lcur = 0;
@@ -577,7 +603,8 @@ __global__ __launch_bounds__(NT) void code_pattern_bwd_roll_kernel(
     for (int r = 0; r < NR; ++r) {
         const int y = y0 - PAD + r;
         const bool ok = colok && y >= 0 && y < H && lv[r] != 255;
-        const float v = ok ? gv[r] * rden : 0.0f;
+        const float gsrc = DOT ? gv[r] - (y == py ? sfix : 0.0f) : gv[r];
+        const float v = ok ? gsrc * rden : 0.0f;
         const int l = ok ? lv[r] : lcur;          // pixels that contribute nothing keep the weights they have
         if (__ballot(l != lcur) != 0ull) {
             lds_read4<KKP>(smem + l * KKP, w);
@@ -1319,6 +1346,10 @@ void code_pattern_bwd_sweep_kernel(
 #endif
 constexpr int kRollRows = FC3D_ROLL_ROWS;         // output rows per strip of the rolling-row kernels: forward,
 constexpr int kRollRowsBwd = FC3D_ROLL_ROWS_BWD;  // backward
+#ifndef FC3D_ROLL_ROWS_BWD_DOT
+#define FC3D_ROLL_ROWS_BWD_DOT 16
+#endif
+constexpr int kRollRowsBwdDot = FC3D_ROLL_ROWS_BWD_DOT;   // backward that is handed sum(g*out): no rows of `out` in registers
 
 constexpr int kBigLdsBudget = 96 * 1024;      // dynamic LDS a kernel may be allowed beyond the 48 KiB default
 template <typename K>
@@ -1507,7 +1538,8 @@ extern "C" int fc3d_code_pattern_bwd(void* stream, const float* g_out, const flo
         const int nstrips = cdiv(W, Roll<KV>::SW);                                                               \
         const dim3 gr(cdiv((long)nstrips * cdiv(H, R), NT / 64), B);                                             \
         FC3D_LAUNCH("code_pattern_bwd", (code_pattern_bwd_roll_kernel<KV, R>), gr, dim3(NT), rlds, s, g_out,     \
-                    out, layer_u8, max_in, psf, H, W, L, nstrips, partial, g_pat0);                              \
+                    out, layer_u8, max_in, psf, H, W, L, nstrips, partial, g_pat0, (const int*)nullptr,          \
+                    (const float*)nullptr, 0);                                                                   \
         FC3D_LAUNCH("code_pattern_bwd_max", code_pattern_bwd_max_kernel, dim3(B), dim3(NT), 0, s,                \
                     (const float*)partial, (int)(gr.x * (NT / 64)), max_in, argmax_i32, layer_u8, psf, H,        \
                     W, KV, g_pat0);                                                                              \
@@ -1537,4 +1569,36 @@ extern "C" int fc3d_code_pattern_bwd(void* stream, const float* g_out, const flo
     FC3D_LAUNCH("code_pattern_bwd", k, dim3(cdiv(W, TX), cdiv(H, TY), B), dim3(NT), lds, s, g_out, layer_u8, max_in,
                 argmax_i32, (const float*)partial, nred, psf, H, W, L, Kh, Kw, conv_flag, cap, g_pat0);
     return FC3D_OK;
+}
+
+extern "C" int fc3d_code_pattern_bwd_dot_supported(int Kh, int Kw, int conv_flag) {
+    return conv_flag && Kh == Kw && (Kw == 3 || Kw == 5 || Kw == 7);
+}
+
+extern "C" int fc3d_code_pattern_bwd_dot(void* stream, const float* g_out, const float* dot_partial, int n_partial,
+                                         const uint8_t* layer_u8, const float* max_in, const int32_t* argmax_i32,
+                                         const float* psf, int B, int H, int W, int L, int Kh, int Kw, int conv_flag,
+                                         float* g_pat0) {
+    if (!g_out || !dot_partial || n_partial <= 0 || !layer_u8 || !max_in || !argmax_i32 || !psf || !g_pat0)
+        return FC3D_EINVAL;
+    if (B <= 0 || H <= 0 || W <= 0 || L <= 0 || L > 254) return FC3D_EINVAL;
+    if (!fc3d_code_pattern_bwd_dot_supported(Kh, Kw, conv_flag)) return FC3D_EINVAL;
+    const long HW = (long)H * W;
+    if ((long)B * HW >= (1L << 31) || B > 65535 || HW >= (1L << 30)) return FC3D_ERANGE;
+    hipStream_t s = (hipStream_t)stream;
+    constexpr int R = kRollRowsBwdDot;
+#define FC3D_BWD_DOT_CASE(KV)                                                                                    \
+    if (Kw == KV) {                                                                                              \
+        const size_t rlds = (size_t)L * Roll<KV>::KKP * sizeof(float);                                           \
+        if (int e = allow_big_lds(code_pattern_bwd_roll_kernel<KV, R, true>, rlds)) return e;                    \
+        const int nstrips = cdiv(W, Roll<KV>::SW);                                                               \
+        const dim3 gr(cdiv((long)nstrips * cdiv(H, R), NT / 64), B);                                             \
+        FC3D_LAUNCH("code_pattern_bwd", (code_pattern_bwd_roll_kernel<KV, R, true>), gr, dim3(NT), rlds, s,      \
+                    g_out, (const float*)nullptr, layer_u8, max_in, psf, H, W, L, nstrips, (float*)nullptr,      \
+                    g_pat0, (const int*)argmax_i32, dot_partial, n_partial);                                     \
+        return FC3D_OK;                                                                                          \
+    }
+    FC3D_BWD_DOT_CASE(3) FC3D_BWD_DOT_CASE(5) FC3D_BWD_DOT_CASE(7)
+#undef FC3D_BWD_DOT_CASE
+    return FC3D_EINVAL;
 }

@@ -88,6 +88,29 @@ def layer_grid(n_layers: int, wvl: float, D: float, z0: float, z_min: float, z_m
     return LayerGrid(np.float32(coeff), np.float32(1 / z0), np.float32(step), c0, n_layers)
 
 
+# A by-product of a backward pass, handed from the operator that produced a gradient tensor to the
+# operator that consumes it: the sampler's image-gradient kernel can sum (gradient * sampled image)
+# over its tiles while it writes the gradient, which is exactly the sum(g * out) codePattern's
+# backward needs for the gradient through its per-image maximum.  It travels as an attribute of the
+# gradient tensor (autograd hands the very same Python object on) and is only honoured if that
+# tensor is unmodified and the consumer's own forward result is the image that was sampled;
+# anything else (gradients accumulated from several consumers -- a new tensor without the
+# attribute --, hooks that rewrite them, other images) takes the ordinary path.
+def _offer_grad_dot(grad: torch.Tensor, img: torch.Tensor, partials: torch.Tensor) -> None:
+    grad._fc3d_dot = (grad._version, img.data_ptr(), img._version, tuple(img.shape), partials)
+
+
+def _take_grad_dot(grad: torch.Tensor, out: torch.Tensor):
+    hit = getattr(grad, "_fc3d_dot", None)
+    if hit is None:
+        return None
+    version, img_ptr, img_version, img_shape, partials = hit
+    if (grad._version != version or not grad.is_contiguous() or img_ptr != out.data_ptr()
+            or img_version != out._version or img_shape != tuple(out.shape)):
+        return None
+    return partials
+
+
 class CodePatternFn(torch.autograd.Function):
     """codePattern on channel 0 of the pattern; optics_pytorch.py:71-121."""
 
@@ -130,8 +153,17 @@ class CodePatternFn(torch.autograd.Function):
         B, H, W, L, Kh, Kw, conv = ctx.meta
         g = _dense(g_out)
         dev = g.device
-        ws = torch.empty(max(1, _lib.fc3d_code_pattern_bwd_workspace(B, H, W) // 4), dtype=torch.float32, device=dev)
         gp = torch.empty((B, H, W, 1), dtype=torch.float32, device=dev)
+        # did the operator that produced g (the sampler's backward) already form sum(g * out)?
+        dot = _take_grad_dot(g_out, out) if _lib.fc3d_code_pattern_bwd_dot_supported(Kh, Kw, int(conv)) else None
+        if dot is not None:
+            with _on_device(dev):
+                _check(_lib.fc3d_code_pattern_bwd_dot(_stream(), g.data_ptr(), dot.data_ptr(), dot.shape[1],
+                                                      layer.data_ptr(), mx.data_ptr(), am.data_ptr(), psf.data_ptr(),
+                                                      B, H, W, L, Kh, Kw, int(conv), gp.data_ptr()),
+                       "fc3d_code_pattern_bwd_dot")
+            return gp, None, None, None, None
+        ws = torch.empty(max(1, _lib.fc3d_code_pattern_bwd_workspace(B, H, W) // 4), dtype=torch.float32, device=dev)
         with _on_device(dev):
             _check(_lib.fc3d_code_pattern_bwd(_stream(), g.data_ptr(), out.data_ptr(), layer.data_ptr(),
                                               mx.data_ptr(), am.data_ptr(), psf.data_ptr() if conv else None,
@@ -284,12 +316,22 @@ def _tap_index_buffer(B, Hs, Ws, Ht, Wt, dev):
     return torch.empty(nbytes // 8, dtype=torch.int64, device=dev) if nbytes else None
 
 
-def _bilinear_bwd_img(g, grid, mask, B, Hs, Ws, C, Ht, Wt, index=None):
+def _bilinear_bwd_img(g, grid, mask, B, Hs, Ws, C, Ht, Wt, index=None, img=None):
     dev = g.device
     ready = index is not None
     if not ready and C == 1 and _img_grad_ordered():
         index = _tap_index_buffer(B, Hs, Ws, Ht, Wt, dev)
     gi = torch.empty((B, Hs, Ws, C), dtype=torch.float32, device=dev)
+    if ready and C == 1 and img is not None and img.is_contiguous():
+        # gather form + the per-tile sums of gi * img on the side (see _offer_grad_dot)
+        n = _lib.fc3d_bilinear_bwd_img_dot_count(Hs, Ws)
+        partials = torch.empty((B, n), dtype=torch.float32, device=dev)
+        with _on_device(dev):
+            _check(_lib.fc3d_bilinear_bwd_img_dot(_stream(), g.data_ptr(), grid.data_ptr(), B, Hs, Ws, Ht, Wt,
+                                                  index.data_ptr(), img.data_ptr(), gi.data_ptr(), partials.data_ptr()),
+                   "fc3d_bilinear_bwd_img_dot")
+        _offer_grad_dot(gi, img, partials)
+        return gi
     with _on_device(dev):
         _check(_lib.fc3d_bilinear_bwd_img(_stream(), g.data_ptr(), grid.data_ptr(),
                                           mask.data_ptr() if mask is not None else None, B, Hs, Ws, C, Ht, Wt,
@@ -474,7 +516,7 @@ class WarpP2CPoseFn(torch.autograd.Function):
             if status != 0 and pooled:
                 _zero_masks.pop(key, None)        # its contents are unknown now
             _check(status, "fc3d_warp_p2c_pose_fwd")
-        ctx.save_for_backward(gc2p, None if pooled else mask, index)
+        ctx.save_for_backward(gc2p, None if pooled else mask, index, ip if index is not None else None)
         ctx.mark_non_differentiable(gp2c, gc2p)
         ctx.set_materialize_grads(False)
         return Ic, gp2c, gc2p
@@ -483,9 +525,9 @@ class WarpP2CPoseFn(torch.autograd.Function):
     def backward(ctx, g_Ic, _g1, _g2):
         if g_Ic is None:
             return None, None, None, None, None
-        gc2p, mask, index = ctx.saved_tensors
+        gc2p, mask, index, ip = ctx.saved_tensors
         B, H, W, _ = gc2p.shape
-        gi = _bilinear_bwd_img(_dense(g_Ic), gc2p, mask, B, H, W, 1, H, W, index=index)
+        gi = _bilinear_bwd_img(_dense(g_Ic), gc2p, mask, B, H, W, 1, H, W, index=index, img=ip)
         return gi, None, None, None, None
 
 

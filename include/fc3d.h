@@ -105,6 +105,18 @@ int fc3d_code_pattern_bwd(void *stream, const float *g_out, const float *out, co
                           int B, int H, int W, int L, int Kh, int Kw, int conv_flag,
                           void *workspace, float *g_pat0);
 
+/* The same backward (autograd of optics_pytorch.py:97-119) when sum(g_out * out) per image is
+ * known already, as n_partial partial sums per image (dot_partial[b * n_partial + i], added here in a
+ * fixed order; fc3d_bilinear_bwd_img_dot produces them while it writes g_out): `out` is not read,
+ * no workspace is needed, and the share of the per-image maximum goes in at its source pixel, so the
+ * whole backward is one launch.  Square 3x3 / 5x5 / 7x7 PSFs with conv_flag set
+ * (fc3d_code_pattern_bwd_dot_supported); FC3D_EINVAL otherwise.                               */
+int fc3d_code_pattern_bwd_dot_supported(int Kh, int Kw, int conv_flag);
+int fc3d_code_pattern_bwd_dot(void *stream, const float *g_out, const float *dot_partial, int n_partial,
+                              const uint8_t *layer_u8, const float *max_in, const int32_t *argmax_i32,
+                              const float *psf, int B, int H, int W, int L, int Kh, int Kw, int conv_flag,
+                              float *g_pat0);
+
 /* ------------------------------------------------------------------------ */
 /* geometry                                                                    */
 /* ------------------------------------------------------------------------ */
@@ -178,6 +190,17 @@ int fc3d_bilinear_tap_index(void *stream, const float *grid, const uint8_t *mask
 int fc3d_bilinear_bwd_img(void *stream, const float *g_out, const float *grid, const uint8_t *mask_u8,
                           int B, int Hs, int Ws, int C, int Ht, int Wt, void *index, int index_ready,
                           float *g_img);
+
+/* The gather form above (C == 1, index ready) that also returns what the backward of a
+ * normalisation of img by one of its own statistics needs -- the inner product of the gradient it
+ * has just formed with img, the image that was sampled (codePattern divides by the per-image
+ * maximum, optics_pytorch.py:118-119; its backward needs sum(g * Ip_coded)): one partial per source
+ * tile, dot_partial[b * n + t], n = fc3d_bilinear_bwd_img_dot_count(Hs, Ws), the sum over tile t of
+ * g_img * img, each tile summed in a fixed order.  fc3d_code_pattern_bwd_dot takes them.        */
+int fc3d_bilinear_bwd_img_dot_count(int Hs, int Ws);
+int fc3d_bilinear_bwd_img_dot(void *stream, const float *g_out, const float *grid, int B, int Hs, int Ws,
+                              int Ht, int Wt, void *index, const float *img, float *g_img,
+                              float *dot_partial);
 
 /* gen_visible_mask, geometry_pytorch.py:180-222.  method 0 = 'all', 1 = 'round'.
  * Either output may be NULL; both are cleared by the call.                    */

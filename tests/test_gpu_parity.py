@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_err
+from conftest import rel_err, rel_err_elem
 
 pytestmark = pytest.mark.gpu
 
@@ -485,6 +485,61 @@ def test_warp_pose_in_kernel_matches_separate_transforms(mods, golden, monkeypat
     tf, ti, a = ops.pose_transforms(pose, K, True, True, True)
     assert torch.equal(mats[0], tf) and torch.equal(mats[1], ti) and torch.equal(mats[2], a)
     assert int(mask.count_nonzero()) > 0            # mask_rezero = 0: the mask stays available
+
+
+@pytest.mark.parametrize("K", [3, 5, 7])
+def test_backward_hands_sum_from_sampler_to_code_pattern(mods, K):
+    """codePattern -> warp_p2c backward: the sampler's image-gradient kernel hands sum(g * Ip_coded) to
+    codePattern's backward (one launch, `out` not read, the maximum's share applied at its source pixel).
+    Same gradient as the ordinary two-launch backward to 1e-6 of the scale and element by element, the
+    hand-off really happens, and it is refused when the gradient was touched on the way."""
+    G, O, ops, synth = mods["G"], mods["O"], mods["ops"], mods["synth"]
+    B, H, W, L = 3, 150, 276, 21                       # ragged: tiles and strips that hang over the image
+    sc = synth.make_scene(B, H, W, seed=31)
+    O.PSFs_np = synth.make_psfs(L, K, "disc")
+    Kmat = dev(np.diag([1666.67, 1666.67, 1, 1]).astype(np.float32))
+    Kmat[0, 2], Kmat[1, 2] = W / 2, H / 2
+    rays = G.pixel_to_ray_array(W, H)
+    coord_p = G.points_in_camera_coords(dev(sc["z_p"]), rays).permute(0, 3, 1, 2)
+    coord_c = G.points_in_camera_coords(dev(sc["z_c"]), rays).permute(0, 3, 1, 2)
+    p0 = synth.make_pattern(sc["z_p"], 5, "uniform")
+    up = dev(np.random.RandomState(6).uniform(0.0, 1.0, (B, H, W, 1)).astype(np.float32))
+    res = {}
+    calls = {"dot": 0, "plain": 0}
+
+    class Spy:
+        def __init__(self, lib):
+            self._lib = lib
+
+        def __getattr__(self, name):
+            if name == "fc3d_code_pattern_bwd_dot":
+                calls["dot"] += 1
+            if name == "fc3d_code_pattern_bwd":
+                calls["plain"] += 1
+            return getattr(self._lib, name)
+    lib = ops._lib
+    ops._lib = Spy(lib)
+    try:
+        for mode in ("handed", "touched", "no_offer"):
+            pat = dev(p0).requires_grad_(True)
+            Ip = O.codePattern(pat, dev(sc["z_p"]), n_layers=L)
+            if mode == "touched":
+                Ip.register_hook(lambda g: g.mul_(1.0))          # in place: same tensor, new version
+            if mode == "no_offer":
+                Ic = G.bilinear_sampler(Ip, G._coord0TOgrid1(coord_c, torch.linalg.inv(dev(sc["pose_p2c"])), Kmat))
+            else:
+                Ic, _, _ = G._warp_p2c(Ip, coord_p, coord_c, dev(sc["pose_p2c"]), Kmat)
+            before = dict(calls)
+            Ic.backward(up)
+            used = {k: calls[k] - before[k] for k in calls}
+            res[mode] = (pat.grad.clone(), used)
+    finally:
+        ops._lib = lib
+    assert res["handed"][1] == {"dot": 1, "plain": 0}
+    assert res["touched"][1] == {"dot": 0, "plain": 1} and res["no_offer"][1] == {"dot": 0, "plain": 1}
+    a, b = res["handed"][0].cpu().numpy(), res["touched"][0].cpu().numpy()
+    assert float(np.abs(b).max()) > 0
+    assert rel_err(a, b) < 1e-6 and rel_err_elem(a, b) < 1e-4
 
 
 def test_warp_differentiable_geometry_path(mods, golden, monkeypatch):
