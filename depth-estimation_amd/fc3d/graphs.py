@@ -28,13 +28,19 @@ class GraphedImageFormation:
     forward results (also static)."""
 
     def __init__(self, pattern, z_p, coord_p, coord_c, pose, upstream_grad, n_layers, is_conv_psf=True,
-                 warmup: int = 3):
+                 warmup: int = 3, unroll: int = 1):
+        """unroll > 1 additionally captures that many consecutive steps as ONE graph (same launches on
+        the same static buffers, back to back), for callers that run many steps on unchanged inputs
+        (benchmarks): `replay_steps(k)` then issues k // unroll launches of it plus k % unroll of the
+        single step, which takes the pause between two graph launches out of all but a few steps."""
         if not (pattern.is_leaf and pattern.requires_grad):
             raise ValueError("pattern must be a leaf tensor that requires grad")
         self.pattern, self.z_p, self.coord_p, self.coord_c, self.pose = pattern, z_p, coord_p, coord_c, pose
         self.upstream_grad, self.n_layers, self.conv = upstream_grad, n_layers, is_conv_psf
         self.outputs = None
         self.graph = None
+        self.unroll = max(1, int(unroll))
+        self.graph_n = None
         self._capture(warmup)
 
     def _step(self):
@@ -63,11 +69,50 @@ class GraphedImageFormation:
             outs = self._step()
         self.graph = g
         self.outputs = tuple(o.detach() for o in outs)
+        self.grad = self.pattern.grad
+        if self.unroll > 1:
+            # the same step `unroll` times in a row.  Every step allocates its results anew from the
+            # graph's pool (blocks freed by one step are reused by the next), so this graph has static
+            # results of its own: those of its last step.
+            gn = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gn, stream=side, capture_error_mode="thread_local"):
+                for _ in range(self.unroll):
+                    self.pattern.grad = None
+                    outs_n = self._step()
+            self.graph_n = gn
+            self.outputs_n = tuple(o.detach() for o in outs_n)
+            self.grad_n = self.pattern.grad
+            self.pattern.grad = self.grad
+        # the first launch of an instantiated graph does one-time work (its kernel arguments go to the
+        # device); do it here, not in the caller's first replay
+        with torch.cuda.stream(side):
+            g.replay()
+            if self.graph_n is not None:
+                self.graph_n.replay()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
 
     def replay(self):
         """Runs the captured step on the current stream; returns (Ic, pattern.grad) static tensors."""
         self.graph.replay()
-        return self.outputs[1], self.pattern.grad
+        self.pattern.grad = self.grad
+        return self.outputs[1], self.grad
+
+    def replay_steps(self, k: int):
+        """k consecutive steps on the current inputs; returns the static (Ic, pattern.grad) of the last."""
+        if k <= 0:
+            raise ValueError("k must be positive")
+        n = k // self.unroll if self.graph_n is not None else 0
+        for _ in range(n):
+            self.graph_n.replay()
+        rest = k - n * self.unroll
+        for _ in range(rest):
+            self.graph.replay()
+        if rest == 0:
+            self.pattern.grad = self.grad_n
+            return self.outputs_n[1], self.grad_n
+        self.pattern.grad = self.grad
+        return self.outputs[1], self.grad
 
 
 class GraphedCapture:
