@@ -1,6 +1,6 @@
 """HIP-graph replay of the image-formation step and of the capture simulator.
 
-One capture (codePattern -> warp_p2c forward, backward to pattern[...,0]) is nine short kernel
+One capture (codePattern -> warp_p2c forward, backward to pattern[...,0]) is six short kernel
 launches; issued one by one from Python (ctypes + autograd) they cost 125-250 us of host time per
 step, which is as much as the kernels themselves take at 32x512x512 and far more at small batches.  Capturing
 the step once into a HIP graph (torch.cuda.CUDAGraph: hipStreamBeginCapture / hipGraphLaunch on
