@@ -714,7 +714,11 @@ void code_pattern_fwd_roll_kernel(
     int lcur = 0;
     lds_read4<KKP>(smem, w);
     float win[NR][K];
-    unsigned long long key = 0;
+    // the lane's maximum so far as value + row (a 64-bit key per pixel costs twice the instructions): a later
+    // row replaces it only if it is greater -- so the first row wins ties, as the position part of the key
+    // would decide -- or if it is the first NaN (torch.max returns NaN once one is present)
+    float best = -INFINITY;
+    int besto = 0;
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         const int y = y0 - PAD + r;
@@ -744,14 +748,19 @@ void code_pattern_fwd_roll_kernel(
                 for (int dx = 0; dx < K; ++dx) a = fmaf(w[dy * K + dx], win[o + dy][dx], a);
             a = a * (l >= 0 ? 1.0f : 0.0f);       // a multiply: a non-finite blur still poisons the pixel
             if (inb) {
-                const uint32_t pos = 0xffffffffu - (uint32_t)(x * H + yo);   // first w, then first h
-                const unsigned long long k = ((unsigned long long)float_to_key(a) << 32) | pos;
-                key = k > key ? k : key;
+                const bool take = (a > best) || (a != a && best == best);
+                best = take ? a : best;
+                besto = take ? o : besto;
                 const unsigned q = (unsigned)(yo * W + x);
                 st_at(rimg, q, a);
                 if (limg) st_at(limg, q, (uint8_t)l);
             }
         }
+    }
+    unsigned long long key = 0;
+    if (mine) {                                   // y0 < H: the lane has stored row 0 at least
+        const uint32_t pos = 0xffffffffu - (uint32_t)(x * H + y0 + besto);   // first w, then first h
+        key = ((unsigned long long)float_to_key(best) << 32) | pos;
     }
     key = wave_max(key);
     if (lane == 0) tilekey[kidx] = key;
