@@ -1204,12 +1204,16 @@ static size_t sweep_bwd_lds() {
 // is what bounds this kernel.  Which staged rows hold a pixel of which layer is kept as one 64-bit
 // set of layers per row (lane r: row r), so that the per-sweep row mask is a single ballot and the
 // skip test of an input row is scalar arithmetic.
-template <int K, int R, int CW>
+// DOT: sum(g*out) arrives as partial sums (see the rolling-row backward): `out` is not read, no partial
+// is written, and the staged cell of the pixel that holds the maximum is lowered by S/den, so the maximum's
+// share is blurred along with everything else.
+template <int K, int R, int CW, bool DOT = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(Sweep<K, R, CW>::BWD_WAVES, Sweep<K, R, CW>::BWD_WAVES)))
 void code_pattern_bwd_sweep_kernel(
     const float* __restrict__ g, const float* __restrict__ out, const uint8_t* __restrict__ layer_u8,
     const float* __restrict__ max_in, const float* __restrict__ psf, int H, int W, int L,
-    float* __restrict__ partial, float* __restrict__ g_pat0) {
+    float* __restrict__ partial, float* __restrict__ g_pat0, const int* __restrict__ argmax_in,
+    const float* __restrict__ dot_partial, int ndot) {
     using S = Sweep<K, R, CW>;
     constexpr int PAD = S::PAD, LW = S::LW, LW0 = S::LW0, LWB = S::LWB, NR = S::NR, NG = S::NG, NRG = R + K - 1;
     constexpr bool PK = S::PK_BWD;
@@ -1257,17 +1261,32 @@ void code_pattern_bwd_sweep_kernel(
         }
         __builtin_amdgcn_sched_barrier(0);                         // keep the batches apart: registers, not latency, are short here
     }
-    // sum of g*out over the pixels this wavefront owns (for the gradient through the per-image maximum)
-    float sgo = 0.0f;
+    if (DOT) {
+        // the maximum's pixel, if this tile stages it (the same test in every lane): cell (pr, pc) of the tile
+        const int am = argmax_in[b];
+        const int pr = am / W - (y0 - HB), pc = am % W - (x0 - HB);
+        if (pr >= 0 && pr < NR && pc >= 0 && pc < LW0) {
+            float sp = 0.0f;
+            for (int i = lane; i < ndot; i += 64) sp += dot_partial[(long)b * ndot + i];
+            sp = wave_sum(sp);
+            const int cellidx = pr * LW + pc;
 #pragma unroll
-    for (int o = 0; o < R; ++o) {
-        const int y = yg + o;
-        const unsigned q = (unsigned)(min(y, H - 1) * W + min(x, W - 1));
-        const float gq = ld_at(g + img, q), ov = ld_at(out + img, q);
-        sgo = fmaf((y < H && x < W) ? gq : 0.0f, ov, sgo);
+            for (int u = 0; u < CPL; ++u)
+                if (u == cellidx / 64 && lane == cellidx % 64) gv[u] -= sp * rden;   // (a pixel without a layer is in no sweep, so nothing comes of it there)
+        }
+    } else {
+        // sum of g*out over the pixels this wavefront owns (for the gradient through the per-image maximum)
+        float sgo = 0.0f;
+#pragma unroll
+        for (int o = 0; o < R; ++o) {
+            const int y = yg + o;
+            const unsigned q = (unsigned)(min(y, H - 1) * W + min(x, W - 1));
+            const float gq = ld_at(g + img, q), ov = ld_at(out + img, q);
+            sgo = fmaf((y < H && x < W) ? gq : 0.0f, ov, sgo);
+        }
+        sgo = wave_sum(sgo);
+        if (lane == 0) partial[((long)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = sgo;
     }
-    sgo = wave_sum(sgo);
-    if (lane == 0) partial[((long)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = sgo;
     __syncthreads();
 
     float acc[R];                                                 // one of the two sets is used, per PK
@@ -1561,7 +1580,8 @@ extern "C" int fc3d_code_pattern_bwd(void* stream, const float* g_out, const flo
         const size_t slds = sweep_bwd_lds<KV, kSweepRows, kSweepCols>();                                         \
         const dim3 gsw(cdiv(W, kSweepCols), cdiv(H, kSweepTileRows), B);                                         \
         FC3D_LAUNCH("code_pattern_bwd", (code_pattern_bwd_sweep_kernel<KV, kSweepRows, kSweepCols>), gsw,        \
-                    dim3(64), slds, s, g_out, out, layer_u8, max_in, psf, H, W, L, partial, g_pat0);             \
+                    dim3(64), slds, s, g_out, out, layer_u8, max_in, psf, H, W, L, partial, g_pat0,              \
+                    (const int*)nullptr, (const float*)nullptr, 0);                                              \
         FC3D_LAUNCH("code_pattern_bwd_max", code_pattern_bwd_max_kernel, dim3(B), dim3(NT), 0, s,                \
                     (const float*)partial, (int)(gsw.x * gsw.y), max_in, argmax_i32, layer_u8, psf, H, W, KV,    \
                     g_pat0);                                                                                     \
@@ -1581,7 +1601,7 @@ extern "C" int fc3d_code_pattern_bwd(void* stream, const float* g_out, const flo
 }
 
 extern "C" int fc3d_code_pattern_bwd_dot_supported(int Kh, int Kw, int conv_flag) {
-    return conv_flag && Kh == Kw && (Kw == 3 || Kw == 5 || Kw == 7);
+    return conv_flag && Kh == Kw && Kw >= 3 && Kw <= 33 && (Kw & 1);
 }
 
 extern "C" int fc3d_code_pattern_bwd_dot(void* stream, const float* g_out, const float* dot_partial, int n_partial,
@@ -1609,5 +1629,16 @@ extern "C" int fc3d_code_pattern_bwd_dot(void* stream, const float* g_out, const
     }
     FC3D_BWD_DOT_CASE(3) FC3D_BWD_DOT_CASE(5) FC3D_BWD_DOT_CASE(7)
 #undef FC3D_BWD_DOT_CASE
+#define FC3D_BWD_DOT_SWEEP_CASE(KV)                                                                              \
+    if (Kw == KV) {                                                                                              \
+        const size_t slds = sweep_bwd_lds<KV, kSweepRows, kSweepCols>();                                         \
+        const dim3 gsw(cdiv(W, kSweepCols), cdiv(H, kSweepTileRows), B);                                         \
+        FC3D_LAUNCH("code_pattern_bwd", (code_pattern_bwd_sweep_kernel<KV, kSweepRows, kSweepCols, true>), gsw,  \
+                    dim3(64), slds, s, g_out, (const float*)nullptr, layer_u8, max_in, psf, H, W, L,             \
+                    (float*)nullptr, g_pat0, (const int*)argmax_i32, dot_partial, n_partial);                    \
+        return FC3D_OK;                                                                                          \
+    }
+    FC3D_FOR_SWEEP_K(FC3D_BWD_DOT_SWEEP_CASE)
+#undef FC3D_BWD_DOT_SWEEP_CASE
     return FC3D_EINVAL;
 }

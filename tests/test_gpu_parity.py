@@ -487,7 +487,7 @@ def test_warp_pose_in_kernel_matches_separate_transforms(mods, golden, monkeypat
     assert int(mask.count_nonzero()) > 0            # mask_rezero = 0: the mask stays available
 
 
-@pytest.mark.parametrize("K", [3, 5, 7])
+@pytest.mark.parametrize("K", [3, 5, 7, 9, 23])
 def test_backward_hands_sum_from_sampler_to_code_pattern(mods, K):
     """codePattern -> warp_p2c backward: the sampler's image-gradient kernel hands sum(g * Ip_coded) to
     codePattern's backward (one launch, `out` not read, the maximum's share applied at its source pixel).
