@@ -296,7 +296,8 @@ def main():
                        "launch": launch, "replay_matches_eager": replay_ok, "bwd": args.bwd},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
-                         "kernel_avg_us": dk["avg_us"], "alg_bytes_per_launch": dk["alg_bytes_per_launch"],
+                         "kernel_avg_us": dk["avg_us"], "kernel_clock": "HIP events on the launching stream (2-4 % above rocprofv3's kernel durations)",
+                         "alg_bytes_per_launch": dk["alg_bytes_per_launch"],
                          "measured_copy_GBps": copy_rate / 1e9,
                          "path_alg_bytes_per_capture": 100 * H * W,
                          "path_frac_per_gpu": (value / world) * 100 * H * W / HBM_PEAK,
