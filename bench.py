@@ -70,6 +70,10 @@ def parse():
     ap.add_argument("--bwd", choices=("ordered", "atomic"), default="ordered",
                     help="gradient of the warp w.r.t. the pattern: ordered = gather form without atomics (fixed "
                          "summation order), atomic = scatter form with global float atomics")
+    ap.add_argument("--overlap", action="store_true",
+                    help="graph launch only: put warp_p2c's projection + splat launch beside codePattern on a second "
+                         "branch of the graph instead of behind it (measured 2-4 us per step slower: the fork and "
+                         "join cost more than the overlap of the two kernels gives)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     return ap.parse_args()
@@ -218,8 +222,8 @@ def main():
         unroll = max(u for u in range(1, 11) if args.steps % u == 0)
         try:
             gf = GraphedImageFormation(tens["pat"], tens["z_p"], tens["coord_p"], tens["coord_c"], tens["pose"],
-                                       tens["g"], tens["L"], unroll=unroll)
-            run_steps, launch = gf.replay_steps, f"hip_graph x{unroll}"
+                                       tens["g"], tens["L"], unroll=unroll, overlap=args.overlap)
+            run_steps, launch = gf.replay_steps, f"hip_graph x{unroll}" + (", projection beside codePattern" if args.overlap else "")
         except Exception as e:   # capture refused (e.g. by another library's activity): measure eager instead
             print(f"[bench] graph capture failed ({type(e).__name__}: {e}); using eager launches", file=sys.stderr)
             torch.cuda.synchronize()

@@ -53,6 +53,8 @@ SIGNATURES = {
                                   P, P, P, P, c_int, P]),
     "fc3d_warp_p2c_pose_fwd": (c_int, [P, P, P, I64, I64, I64, I64, P, I64, I64, I64, I64, P, P, I64, c_int, c_int,
                                        c_int, P, P, P, P, c_int, c_int, P, P, P, P]),
+    "fc3d_warp_project_splat": (c_int, [P, P, I64, I64, I64, I64, P, P, I64, c_int, c_int, c_int, P, P, c_int, P, P, P]),
+    "fc3d_warp_sample": (c_int, [P, P, P, I64, I64, I64, I64, P, c_int, c_int, c_int, P, c_int, P, P, P]),
     "fc3d_points_fwd": (c_int, [P, P, P, P, P, I64, c_int, c_int, c_int, P]),
     "fc3d_points_bwd": (c_int, [P, P, P, P, P, I64, c_int, c_int, c_int, P]),
     "fc3d_reproject_fwd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P]),

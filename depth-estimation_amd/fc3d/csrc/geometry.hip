@@ -1577,46 +1577,51 @@ extern "C" int fc3d_visible_mask(void* stream, const float* grid, int B, int H, 
     return FC3D_OK;
 }
 
-// warp_p2c forward.  pose == NULL: the transforms T_p2c / T_c2p are inputs.  Otherwise they are
-// outputs: the projection kernel forms them from pose and K (no separate pose_transforms launch).
-static int warp_p2c_launch(void* stream, const float* Ip, const float* coord_p, int64_t p_sb, int64_t p_sc,
-                           int64_t p_sh, int64_t p_sw, const float* coord_c, int64_t c_sb, int64_t c_sc,
-                           int64_t c_sh, int64_t c_sw, float* T_p2c, float* T_c2p, const float* pose,
-                           const float* K, int64_t k_sb, float* inv_out, int B, int H, int W, float* Ic_masked,
-                           float* grid_p2c, float* grid_c2p, uint8_t* mask_u8, int mask_is_clear, int mask_rezero,
-                           void* tap_index) {
-    if (!Ip || !coord_p || !coord_c || !T_p2c || !T_c2p || !Ic_masked || !grid_p2c || !grid_c2p || !mask_u8)
-        return FC3D_EINVAL;
+// warp_p2c forward in its two launches.
+// 1. projection of coord_p + visibility splat.  pose == NULL: the transform T_p2c is an input.  Otherwise
+//    T_p2c / T_c2p / inv are outputs: the kernel forms them from pose and K (no separate pose_transforms launch).
+static int launch_project_splat(hipStream_t s, const float* coord_p, int64_t p_sb, int64_t p_sc, int64_t p_sh,
+                                int64_t p_sw, float* T_p2c, float* T_c2p, const float* pose, const float* K,
+                                int64_t k_sb, float* inv_out, int B, int H, int W, float* grid_p2c, uint8_t* mask_u8,
+                                int mask_is_clear) {
+    if (!coord_p || !T_p2c || !grid_p2c || !mask_u8 || (pose && (!K || !T_c2p))) return FC3D_EINVAL;
     if (int e = check_img(B, H, W)) return e;
-    if ((long)H * W >= (1L << 29)) return FC3D_ERANGE;   // per-image byte offsets of the taps are 32-bit
-    if (tap_index && (!gather_fits(H, W, H, W) || (reinterpret_cast<uintptr_t>(tap_index) & 7u))) return FC3D_ERANGE;
-    if (!aligned4(coord_p) || !aligned4(coord_c) || !aligned4(Ip) || !aligned4(Ic_masked) ||
-        (reinterpret_cast<uintptr_t>(grid_p2c) & 7u) || (reinterpret_cast<uintptr_t>(grid_c2p) & 7u))
-        return FC3D_EALIGN;
-    hipStream_t s = (hipStream_t)stream;
+    if ((long)H * W >= (1L << 29)) return FC3D_ERANGE;
+    if (!aligned4(coord_p) || (reinterpret_cast<uintptr_t>(grid_p2c) & 7u)) return FC3D_EALIGN;
     const bool fma = use_fma(H, W);
     dim3 g(cdiv((long)H * W, PX_PER_BLOCK), B), blk(NT);
     if (!mask_is_clear) {
         if (int e = zero_fill(s, mask_u8, (size_t)B * H * W)) return e;
     }
-    {
-        const int layout = pick_layout(coord_p, p_sc, p_sh, p_sw, W);
-        const PoseArgs pa = {pose, K, (long)k_sb, T_p2c, T_c2p, inv_out};
+    const int layout = pick_layout(coord_p, p_sc, p_sh, p_sw, W);
+    const PoseArgs pa = {pose, K, (long)k_sb, T_p2c, T_c2p, inv_out};
 #define ARGS coord_p, (long)p_sb, (long)p_sc, (long)p_sh, (long)p_sw, (const float*)T_p2c, H, W, grid_p2c, mask_u8, pa
-        if (pose) FC3D_DISPATCH_LAYOUT("warp_project_splat", project_kernel, layout, fma, true, true);
-        else FC3D_DISPATCH_LAYOUT("warp_project_splat", project_kernel, layout, fma, true);
+    if (pose) FC3D_DISPATCH_LAYOUT("warp_project_splat", project_kernel, layout, fma, true, true);
+    else FC3D_DISPATCH_LAYOUT("warp_project_splat", project_kernel, layout, fma, true);
 #undef ARGS
-        FC3D_LAUNCH_CHECK();
-    }
-    {
-        const int layout = pick_layout(coord_c, c_sc, c_sh, c_sw, W);
-        // 2: runs of 64*PPL bytes start 16-byte aligned in every image, so they can be cleared with 16-byte stores
-        const int rezero = !mask_rezero ? 0 : ((aligned16(mask_u8) && ((long)H * W) % 16 == 0) ? 2 : 1);
-#define ARGS coord_c, (long)c_sb, (long)c_sc, (long)c_sh, (long)c_sw, (const float*)T_c2p, Ip, mask_u8, rezero, H, W, grid_c2p, Ic_masked, tap_index, B
-        FC3D_DISPATCH_LAYOUT("warp_sample", warp_sample_kernel, layout, fma);
+    FC3D_LAUNCH_CHECK();
+    return FC3D_OK;
+}
+
+// 2. projection of coord_c, sampling of Ip, compositing with the mask (and the tap index on the side)
+static int launch_warp_sample(hipStream_t s, const float* Ip, const float* coord_c, int64_t c_sb, int64_t c_sc,
+                              int64_t c_sh, int64_t c_sw, const float* T_c2p, int B, int H, int W, uint8_t* mask_u8,
+                              int mask_rezero, float* Ic_masked, float* grid_c2p, void* tap_index) {
+    if (!Ip || !coord_c || !T_c2p || !Ic_masked || !grid_c2p || !mask_u8) return FC3D_EINVAL;
+    if (int e = check_img(B, H, W)) return e;
+    if ((long)H * W >= (1L << 29)) return FC3D_ERANGE;   // per-image byte offsets of the taps are 32-bit
+    if (tap_index && (!gather_fits(H, W, H, W) || (reinterpret_cast<uintptr_t>(tap_index) & 7u))) return FC3D_ERANGE;
+    if (!aligned4(coord_c) || !aligned4(Ip) || !aligned4(Ic_masked) || (reinterpret_cast<uintptr_t>(grid_c2p) & 7u))
+        return FC3D_EALIGN;
+    const bool fma = use_fma(H, W);
+    dim3 g(cdiv((long)H * W, PX_PER_BLOCK), B), blk(NT);
+    const int layout = pick_layout(coord_c, c_sc, c_sh, c_sw, W);
+    // 2: runs of 64*PPL bytes start 16-byte aligned in every image, so they can be cleared with 16-byte stores
+    const int rezero = !mask_rezero ? 0 : ((aligned16(mask_u8) && ((long)H * W) % 16 == 0) ? 2 : 1);
+#define ARGS coord_c, (long)c_sb, (long)c_sc, (long)c_sh, (long)c_sw, T_c2p, Ip, mask_u8, rezero, H, W, grid_c2p, Ic_masked, tap_index, B
+    FC3D_DISPATCH_LAYOUT("warp_sample", warp_sample_kernel, layout, fma);
 #undef ARGS
-        FC3D_LAUNCH_CHECK();
-    }
+    FC3D_LAUNCH_CHECK();
     return FC3D_OK;
 }
 
@@ -1625,9 +1630,29 @@ extern "C" int fc3d_warp_p2c_fwd(void* stream, const float* Ip, const float* coo
                                  int64_t c_sh, int64_t c_sw, const float* T_p2c, const float* T_c2p, int B, int H,
                                  int W, float* Ic_masked, float* grid_p2c, float* grid_c2p, uint8_t* mask_u8,
                                  int mask_is_clear, void* tap_index) {
-    return warp_p2c_launch(stream, Ip, coord_p, p_sb, p_sc, p_sh, p_sw, coord_c, c_sb, c_sc, c_sh, c_sw,
-                           const_cast<float*>(T_p2c), const_cast<float*>(T_c2p), nullptr, nullptr, 0, nullptr, B, H, W,
-                           Ic_masked, grid_p2c, grid_c2p, mask_u8, mask_is_clear, 0, tap_index);
+    if (!Ip || !coord_c || !T_c2p || !Ic_masked || !grid_c2p) return FC3D_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (int e = launch_project_splat(s, coord_p, p_sb, p_sc, p_sh, p_sw, const_cast<float*>(T_p2c), nullptr, nullptr,
+                                     nullptr, 0, nullptr, B, H, W, grid_p2c, mask_u8, mask_is_clear))
+        return e;
+    return launch_warp_sample(s, Ip, coord_c, c_sb, c_sc, c_sh, c_sw, T_c2p, B, H, W, mask_u8, 0, Ic_masked, grid_c2p,
+                              tap_index);
+}
+
+extern "C" int fc3d_warp_project_splat(void* stream, const float* coord_p, int64_t p_sb, int64_t p_sc, int64_t p_sh,
+                                       int64_t p_sw, const float* pose, const float* K, int64_t k_sb, int B, int H,
+                                       int W, float* grid_p2c, uint8_t* mask_u8, int mask_is_clear, float* T_p2c_out,
+                                       float* T_c2p_out, float* inv_out) {
+    if (!pose || !K) return FC3D_EINVAL;
+    return launch_project_splat((hipStream_t)stream, coord_p, p_sb, p_sc, p_sh, p_sw, T_p2c_out, T_c2p_out, pose, K,
+                                k_sb, inv_out, B, H, W, grid_p2c, mask_u8, mask_is_clear);
+}
+
+extern "C" int fc3d_warp_sample(void* stream, const float* Ip, const float* coord_c, int64_t c_sb, int64_t c_sc,
+                                int64_t c_sh, int64_t c_sw, const float* T_c2p, int B, int H, int W, uint8_t* mask_u8,
+                                int mask_rezero, float* Ic_masked, float* grid_c2p, void* tap_index) {
+    return launch_warp_sample((hipStream_t)stream, Ip, coord_c, c_sb, c_sc, c_sh, c_sw, T_c2p, B, H, W, mask_u8,
+                              mask_rezero, Ic_masked, grid_c2p, tap_index);
 }
 
 extern "C" int fc3d_warp_p2c_pose_fwd(void* stream, const float* Ip, const float* coord_p, int64_t p_sb, int64_t p_sc,
@@ -1636,10 +1661,13 @@ extern "C" int fc3d_warp_p2c_pose_fwd(void* stream, const float* Ip, const float
                                       int B, int H, int W, float* Ic_masked, float* grid_p2c, float* grid_c2p,
                                       uint8_t* mask_u8, int mask_is_clear, int mask_rezero, void* tap_index,
                                       float* T_p2c_out, float* T_c2p_out, float* inv_out) {
-    if (!pose || !K) return FC3D_EINVAL;
-    return warp_p2c_launch(stream, Ip, coord_p, p_sb, p_sc, p_sh, p_sw, coord_c, c_sb, c_sc, c_sh, c_sw, T_p2c_out,
-                           T_c2p_out, pose, K, k_sb, inv_out, B, H, W, Ic_masked, grid_p2c, grid_c2p, mask_u8,
-                           mask_is_clear, mask_rezero, tap_index);
+    if (!pose || !K || !Ip || !coord_c || !Ic_masked || !grid_c2p) return FC3D_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (int e = launch_project_splat(s, coord_p, p_sb, p_sc, p_sh, p_sw, T_p2c_out, T_c2p_out, pose, K, k_sb, inv_out, B,
+                                     H, W, grid_p2c, mask_u8, mask_is_clear))
+        return e;
+    return launch_warp_sample(s, Ip, coord_c, c_sb, c_sc, c_sh, c_sw, T_c2p_out, B, H, W, mask_u8, mask_rezero, Ic_masked,
+                              grid_c2p, tap_index);
 }
 
 extern "C" int fc3d_points_fwd(void* stream, const float* z, const float* ray_x, const float* ray_y,

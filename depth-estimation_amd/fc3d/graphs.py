@@ -28,11 +28,12 @@ class GraphedImageFormation:
     forward results (also static)."""
 
     def __init__(self, pattern, z_p, coord_p, coord_c, pose, upstream_grad, n_layers, is_conv_psf=True,
-                 warmup: int = 3, unroll: int = 1):
+                 warmup: int = 3, unroll: int = 1, overlap: bool = False):
         """unroll > 1 additionally captures that many consecutive steps as ONE graph (same launches on
         the same static buffers, back to back), for callers that run many steps on unchanged inputs
         (benchmarks): `replay_steps(k)` then issues k // unroll launches of it plus k % unroll of the
-        single step, which takes the pause between two graph launches out of all but a few steps."""
+        single step, which takes the pause between two graph launches out of all but a few steps.
+        overlap=True captures warp_p2c's projection + splat launch as a second branch beside codePattern."""
         if not (pattern.is_leaf and pattern.requires_grad):
             raise ValueError("pattern must be a leaf tensor that requires grad")
         self.pattern, self.z_p, self.coord_p, self.coord_c, self.pose = pattern, z_p, coord_p, coord_c, pose
@@ -41,11 +42,25 @@ class GraphedImageFormation:
         self.graph = None
         self.unroll = max(1, int(unroll))
         self.graph_n = None
+        # overlap: warp_p2c's first launch runs beside codePattern on a second stream (see _step)
+        self.fork = torch.cuda.Stream(device=pattern.device) if overlap else None
         self._capture(warmup)
 
     def _step(self):
-        Ip = O.codePattern(self.pattern, self.z_p, is_conv_psf=self.conv, n_layers=self.n_layers)
-        Ic, gp2c, gc2p = G.warp_p2c(Ip, self.coord_p, self.coord_c, self.pose)
+        if self.fork is None:
+            Ip = O.codePattern(self.pattern, self.z_p, is_conv_psf=self.conv, n_layers=self.n_layers)
+            Ic, gp2c, gc2p = G.warp_p2c(Ip, self.coord_p, self.coord_c, self.pose)
+        else:
+            # the forward warp of coord_p (projection + visibility splat, bound by memory) needs nothing from
+            # codePattern (bound by vector instructions): it goes to a second stream -- a second branch of
+            # the graph -- and the two share the chip
+            main = torch.cuda.current_stream()
+            self.fork.wait_stream(main)
+            with torch.cuda.stream(self.fork):
+                begun = G.warp_p2c_begin(self.coord_p, self.pose)
+            Ip = O.codePattern(self.pattern, self.z_p, is_conv_psf=self.conv, n_layers=self.n_layers)
+            main.wait_stream(self.fork)
+            Ic, gp2c, gc2p = G.warp_p2c_finish(Ip, self.coord_c, begun)
         Ic.backward(self.upstream_grad)
         return Ip, Ic, gp2c, gc2p
 

@@ -531,6 +531,95 @@ class WarpP2CPoseFn(torch.autograd.Function):
         return gi, None, None, None, None
 
 
+class WarpBegun:
+    """What the first launch of warp_p2c (projection of coord_p + visibility splat) leaves for the second."""
+    __slots__ = ("grid_p2c", "mask", "transforms", "pooled", "pool_key", "shape")
+
+
+def warp_p2c_begin(coord_p: torch.Tensor, pose: torch.Tensor, K: torch.Tensor) -> WarpBegun:
+    """The half of warp_p2c that needs neither the image nor coord_c (geometry_pytorch.py:276-277): grid_p2c,
+    the visibility mask, and K*pose / K*inverse(pose) formed on the side.  It may be issued on another stream,
+    beside the work that produces the image; the caller orders that stream before WarpSampleFn."""
+    dev = _need_gpu(coord_p, pose, K)
+    coord_p, sp = _coord_args(coord_p.detach())
+    B, _, H, W = coord_p.shape
+    if tuple(pose.shape) != (B, 4, 4):
+        raise RuntimeError(f"pose must be [{B},4,4], got {tuple(pose.shape)}")
+    po = _dense(pose.detach())
+    K, k_sb = _intrinsics_args(K, B)
+    h = WarpBegun()
+    h.shape = (B, H, W)
+    h.grid_p2c = torch.empty((B, H, W, 2), dtype=torch.float32, device=dev)
+    h.transforms = torch.empty((2, B, 4, 4), dtype=torch.float32, device=dev)
+    with _on_device(dev):
+        s = _stream()
+        h.pool_key = h.mask = None
+        if _img_grad_ordered():        # the atomic form of the image gradient reads the mask again: no pooling then
+            h.pool_key, h.mask = _pooled_zero_mask(B, H, W, dev, s, torch.cuda.is_current_stream_capturing())
+        h.pooled = h.mask is not None
+        if not h.pooled:
+            h.mask = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+        status = _lib.fc3d_warp_project_splat(s, coord_p.data_ptr(), sp[0], sp[1], sp[2], sp[3], po.data_ptr(),
+                                              K.data_ptr(), k_sb, B, H, W, h.grid_p2c.data_ptr(), h.mask.data_ptr(),
+                                              int(h.pooled), h.transforms[0].data_ptr(), h.transforms[1].data_ptr(),
+                                              None)
+        if status != 0 and h.pooled:
+            _zero_masks.pop(h.pool_key, None)
+        _check(status, "fc3d_warp_project_splat")
+    return h
+
+
+class WarpSampleFn(torch.autograd.Function):
+    """The second half of warp_p2c (geometry_pytorch.py:271-273, :279) after warp_p2c_begin: (Ic_masked,
+    grid_c2p); gradient w.r.t. Ip only."""
+
+    @staticmethod
+    def forward(ctx, Ip, coord_c, begun: WarpBegun):
+        dev = _need_gpu(Ip, coord_c)
+        coord_c, sc = _coord_args(coord_c)
+        B, H, W = begun.shape
+        if tuple(coord_c.shape) != (B, 4, H, W) or tuple(Ip.shape) != (B, H, W, 1):
+            raise RuntimeError(f"warp_p2c: Ip {tuple(Ip.shape)}, coord_c {tuple(coord_c.shape)} after a first half "
+                               f"for {B}x{H}x{W}")
+        if begun.mask is None:
+            raise RuntimeError("this first half of warp_p2c has been finished already")
+        ip = _dense(Ip)
+        Ic = torch.empty((B, H, W, 1), dtype=torch.float32, device=dev)
+        gc2p = torch.empty((B, H, W, 2), dtype=torch.float32, device=dev)
+        want_grad = ctx.needs_input_grad[0]
+        index = _tap_index_buffer(B, H, W, H, W, dev) if (want_grad and _img_grad_ordered()) else None
+        if want_grad and index is None and begun.pooled:
+            raise RuntimeError("the image-gradient mode changed between the two halves of warp_p2c")
+        mask, begun.mask = begun.mask, None
+        with _on_device(dev):
+            if not torch.cuda.is_current_stream_capturing():
+                # the first half may have run (and allocated) on another stream: tell the allocator who reads
+                here = torch.cuda.current_stream()
+                begun.transforms.record_stream(here)
+                if not begun.pooled:
+                    mask.record_stream(here)
+            status = _lib.fc3d_warp_sample(_stream(), ip.data_ptr(), coord_c.data_ptr(), sc[0], sc[1], sc[2], sc[3],
+                                           begun.transforms[1].data_ptr(), B, H, W, mask.data_ptr(), int(begun.pooled),
+                                           Ic.data_ptr(), gc2p.data_ptr(),
+                                           index.data_ptr() if index is not None else None)
+            if status != 0 and begun.pooled:
+                _zero_masks.pop(begun.pool_key, None)
+            _check(status, "fc3d_warp_sample")
+        ctx.save_for_backward(gc2p, None if begun.pooled else mask, index, ip if index is not None else None)
+        ctx.mark_non_differentiable(gc2p)
+        ctx.set_materialize_grads(False)
+        return Ic, gc2p
+
+    @staticmethod
+    def backward(ctx, g_Ic, _g1):
+        if g_Ic is None:
+            return None, None, None
+        gc2p, mask, index, ip = ctx.saved_tensors
+        B, H, W, _ = gc2p.shape
+        gi = _bilinear_bwd_img(_dense(g_Ic), gc2p, mask, B, H, W, 1, H, W, index=index, img=ip)
+        return gi, None, None
+
+
 class PointsFn(torch.autograd.Function):
     """points_in_camera_coords; geometry_pytorch.py:44-65.  Returns [B,H,W,4].
     Differentiable in z_map only: the rays are constants of the camera in the reference

@@ -210,6 +210,22 @@ def _warp_p2c(Ip, coord_p, coord_c, pose_p2c, K):
     return _ops.WarpP2CPoseFn.apply(Ip, coord_p, coord_c, pose_p2c, K)
 
 
+def warp_p2c_begin(coord_p, pose_p2c, K=None):
+    """First half of warp_p2c for callers that want to overlap it with the production of Ip: the forward
+    warp of coord_p and the visibility splat (geometry_pytorch.py:276-277) depend on neither Ip nor
+    coord_c.  Issue it on another stream, order that stream before warp_p2c_finish.  No gradients
+    w.r.t. coord_p / pose on this route (use warp_p2c for those)."""
+    if K is None:
+        K = _intrinsics_for(coord_p.shape[0], coord_p.device)
+    return _ops.warp_p2c_begin(coord_p, pose_p2c, K)
+
+
+def warp_p2c_finish(Ip, coord_c, begun):
+    """Second half: (Ic_masked, grid_p2c, grid_c2p) exactly as warp_p2c returns them."""
+    Ic, grid_c2p = _ops.WarpSampleFn.apply(Ip, coord_c, begun)
+    return Ic, begun.grid_p2c, grid_c2p
+
+
 def zp_cView_to_zc(zp_cView, pose_p2c, xy):
     """Projector-frame depth seen from the camera -> camera-frame depth
     (geometry_pytorch.py:284-308)."""

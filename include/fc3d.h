@@ -238,6 +238,21 @@ int fc3d_warp_p2c_pose_fwd(void *stream, const float *Ip,
                            int mask_is_clear, int mask_rezero, void *tap_index,
                            float *T_p2c_out, float *T_c2p_out, float *inv_out);
 
+/* The two launches of fc3d_warp_p2c_pose_fwd on their own, for callers that issue them apart -- the
+ * first (geometry_pytorch.py:276-277 with :103-104: projection of coord_p and the visibility splat)
+ * needs neither Ip nor coord_c, so it can run on another stream beside the work that produces Ip;
+ * the second (:271-273, :279) needs the mask and T_c2p_out of the first.  Same arguments and
+ * results as in fc3d_warp_p2c_pose_fwd.                                                         */
+int fc3d_warp_project_splat(void *stream,
+                            const float *coord_p, int64_t p_sb, int64_t p_sc, int64_t p_sh, int64_t p_sw,
+                            const float *pose, const float *K, int64_t k_sb, int B, int H, int W,
+                            float *grid_p2c, uint8_t *mask_u8, int mask_is_clear,
+                            float *T_p2c_out, float *T_c2p_out, float *inv_out);
+int fc3d_warp_sample(void *stream, const float *Ip,
+                     const float *coord_c, int64_t c_sb, int64_t c_sc, int64_t c_sh, int64_t c_sw,
+                     const float *T_c2p, int B, int H, int W, uint8_t *mask_u8, int mask_rezero,
+                     float *Ic_masked, float *grid_c2p, void *tap_index);
+
 /* points_in_camera_coords, geometry_pytorch.py:44-65: out [B][H][W][4] =
  * (z*rx, z*ry, z*rz, 1).  Rays either separable (ray_x[W], ray_y[H], rz = 1:
  * the table pixel_to_ray_array :30-41 produces) or a dense table with batch

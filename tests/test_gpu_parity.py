@@ -482,6 +482,24 @@ def test_warp_pose_in_kernel_matches_separate_transforms(mods, golden, monkeypat
         tf, ti, _ = ops.pose_transforms(dev(sc["pose_p2c"]), Kr, want_fwd=True, want_inv=True)
         b2 = ops.WarpP2CFn.apply(ipr, cp, cc, tf, ti, None)
         assert all(torch.equal(x, y) for x, y in zip(a, b2[:3])), rep
+    # the two halves issued apart, the first on another stream: what warp_p2c gives, gradient included
+    side = torch.cuda.Stream()
+    for rep in range(2):
+        ip1 = ipr.clone().requires_grad_(True)
+        ip2 = ipr.clone().requires_grad_(True)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            begun = G.warp_p2c_begin(cp, dev(sc["pose_p2c"]), Kr)
+        torch.cuda.current_stream().wait_stream(side)
+        a = G.warp_p2c_finish(ip1, cc, begun)
+        b3 = G._warp_p2c(ip2, cp, cc, dev(sc["pose_p2c"]), Kr)
+        assert all(torch.equal(x, y) for x, y in zip(a, b3)), rep
+        up = torch.ones_like(a[0])
+        a[0].backward(up)
+        b3[0].backward(up)
+        assert torch.equal(ip1.grad, ip2.grad)
+        with pytest.raises(RuntimeError):
+            G.warp_p2c_finish(ip1, cc, begun)       # a first half is good for one second half
     for m in ops._zero_masks.values():
         assert int(m.count_nonzero()) == 0          # every pooled mask is back to zeros
     # the matrices written on the side
