@@ -69,6 +69,9 @@ SIGNATURES = {
     "fc3d_capture_warp_fwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, P, P, P, c_int, P, P]),
     "fc3d_capture_post_workspace": (c_size_t, [c_int, c_int, c_int]),
     "fc3d_capture_post": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, P, P, P]),
+    "fc3d_capture_fwd_workspace": (c_size_t, [c_int, c_int, c_int]),
+    "fc3d_capture_fwd": (c_int, [P, P, P, P, P, P, P, P, I64, P, P, P, c_int, c_int, c_int, P, P, P, P, P, c_int, c_int,
+                                 P, P, P]),
     "fc3d_box_filter": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_float, P]),
     "fc3d_profile_enable": (c_int, [c_int]),
     "fc3d_profile_report": (c_int, [c_char_p, c_size_t]),

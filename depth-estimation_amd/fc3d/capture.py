@@ -165,11 +165,9 @@ def forward_model(z_p, z_c, pose_p2c, n_layers=21, is_conv_psf=True, crop=None, 
             Ip_coded = O.codePattern(ops.reflectance(Ip0, z_p), z_p, is_conv_psf=True, n_layers=n_layers)
         else:                                                   # the training mode: shading and gating in one pass
             Ip_coded = ops.code_pattern_shaded(Ip0, z_p, O._layer_grid(n_layers))
-        # the launch that forms the two transforms also clears the visibility mask for the splat
-        mask = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
-        T_p2c, T_c2p, _ = ops.pose_transforms(pose_p2c.detach(), K, want_fwd=True, want_inv=True, clear=mask)
-        Ic, xyz_cView, mask = ops.capture_warp(Ip_coded, z_p, z_c, rx, ry, T_p2c, T_c2p, zero_mask=mask)
-        Ic_scaled, Ic_mask = ops.capture_post(Ic, noise["offset"], noise["gauss"], noise["scale"], mask)
+        # three launches: forward warp (forms K*pose itself), inverse warp (+ the sensor's peak), sensor model
+        Ic, xyz_cView, Ic_scaled, Ic_mask = ops.capture_fwd(Ip_coded, z_p, z_c, rx, ry, pose_p2c, K, noise["offset"],
+                                                            noise["gauss"], noise["scale"])
         return (c(Ic_scaled), c(Ic_mask), c(xyz_cView), c(xy), c(z_c), c(z_p), pose_p2c, z_p, c(Ic), Ip_coded,
                 Ic_scaled)
     rays = G.pixel_to_ray_array(W, H)

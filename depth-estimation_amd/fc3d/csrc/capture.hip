@@ -73,22 +73,30 @@ __device__ __forceinline__ void point_of(float z, const float* __restrict__ ray_
 // 25 us at 32x512x512, 14 us of it without the four one-byte splat stores per pixel).
 constexpr int CPX = 4;
 
-template <bool FMA>
+// POSE: K*pose is formed here (and K*inverse(pose) left in memory for the inverse warp) instead of read.
+template <bool FMA, bool POSE = false>
 __global__ __launch_bounds__(NT) void capture_project_kernel(const float* __restrict__ z_p,
                                                              const float* __restrict__ ray_x,
                                                              const float* __restrict__ ray_y,
                                                              const float* __restrict__ Tm, int H, int W,
-                                                             float* __restrict__ grid, uint8_t* __restrict__ mask_u8) {
+                                                             float* __restrict__ grid, uint8_t* __restrict__ mask_u8,
+                                                             PoseArgs pa) {
     const int b = blockIdx.y;
     const long HW = (long)H * W;
     const long p0 = (long)blockIdx.x * (NT * CPX) + (threadIdx.x >> 6) * (64 * CPX) + (threadIdx.x & 63);
-    const float* T = Tm + (long)b * 16;
     const float* zb = z_p + (long)b * HW;
     float z[CPX];
 #pragma unroll
     for (int i = 0; i < CPX; ++i) {
         const long p = p0 + 64 * i;
         z[i] = zb[p < HW ? p : HW - 1];
+    }
+    float T[16];
+    if (POSE) {
+        form_transform(pa, b, T);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) T[k] = Tm[(long)b * 16 + k];
     }
     float2* go = grid ? reinterpret_cast<float2*>(grid) + (long)b * HW : nullptr;
     uint8_t* m = mask_u8 + (long)b * HW;
@@ -103,6 +111,25 @@ __global__ __launch_bounds__(NT) void capture_project_kernel(const float* __rest
             splat_px<uint8_t>(m, gx, gy, W, HW, 0, (uint8_t)1);
         }
     }
+}
+
+// torch.max's ordering: a NaN wins and then stays.
+__device__ __forceinline__ float max_nan(float m, float e) { return (e > m || e != e) ? e : m; }
+
+__device__ __forceinline__ float exposed(float ic, float off005, float g) {
+    return __fadd_rn(__fadd_rn(ic, off005), __fmul_rn(g, 0.005f));
+}
+
+__device__ __forceinline__ float block_max_nan(float m, float* sh) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max_nan(m, __shfl_xor(m, o, 64));
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) sh[wave] = m;
+    __syncthreads();
+    float r = sh[0];
+#pragma unroll
+    for (int w = 1; w < NT / 64; ++w) r = max_nan(r, sh[w]);
+    return r;
 }
 
 // Inverse warp: camera pixel -> projector pixel; samples the coded pattern and the projector-frame
@@ -120,7 +147,9 @@ __global__ __launch_bounds__(NT) void capture_sample_kernel(const float* __restr
                                                             const float* __restrict__ z_p,
                                                             const uint8_t* __restrict__ mask_u8, int H, int W,
                                                             float* __restrict__ grid, float* __restrict__ Ic,
-                                                            float* __restrict__ xyz) {
+                                                            float* __restrict__ xyz, const float* __restrict__ offset,
+                                                            const float* __restrict__ gauss,
+                                                            float* __restrict__ peak_partial) {
     const int b = blockIdx.y;
     const long HW = (long)H * W;
     const long p0 = lane_first_pixel();
@@ -129,13 +158,15 @@ __global__ __launch_bounds__(NT) void capture_sample_kernel(const float* __restr
     const float* img = Ip + (long)b * HW;
     const float* zp = z_p + (long)b * HW;
     const uint8_t* mk = mask_u8 + (long)b * HW;
-    float z[PPL], mv[PPL];
+    float z[PPL], mv[PPL], gn[PPL];
 #pragma unroll
     for (int i = 0; i < PPL; ++i) {
         const long p = p0 + 64 * i;
+        gn[i] = 0.0f;
         if (p < HW) {
             z[i] = zb[p];
             mv[i] = (float)mk[p];
+            if (peak_partial) gn[i] = gauss[(long)b * HW + p];
         }
     }
     extern __shared__ float ray_lds[];    // [W] ray_x, then [H] ray_y
@@ -169,16 +200,27 @@ __global__ __launch_bounds__(NT) void capture_sample_kernel(const float* __restr
     float2* go = grid ? reinterpret_cast<float2*>(grid) + (long)b * HW : nullptr;
     float* oo = Ic + (long)b * HW;
     float* xo = xyz + (long)b * HW * 3;
+    // the sensor model's per-image peak (max of Ic + exposure offset + read noise) on the side: one partial
+    // maximum per workgroup, so that no separate pass over Ic and the noise is needed for it
+    float peak = -INFINITY;
+    const float off005 = peak_partial ? __fmul_rn(offset[b], 0.05f) : 0.0f;
 #pragma unroll
     for (int i = 0; i < PPL; ++i) {
         const long p = p0 + 64 * i;
         if (p < HW) {
             if (go) go[p] = make_float2(gx[i], gy[i]);
-            oo[p] = __fmul_rn(blend(t[i], i00[i], i01[i], i10[i], i11[i]), mv[i]);
+            const float icv = __fmul_rn(blend(t[i], i00[i], i01[i], i10[i], i11[i]), mv[i]);
+            peak = max_nan(peak, exposed(icv, off005, gn[i]));
+            oo[p] = icv;
             xo[p * 3 + 0] = __fmul_rn(blend(t[i], rx0[i], rx0[i], rx1[i], rx1[i]), mv[i]);
             xo[p * 3 + 1] = __fmul_rn(blend(t[i], ry0[i], ry1[i], ry0[i], ry1[i]), mv[i]);
             xo[p * 3 + 2] = __fmul_rn(blend(t[i], z00[i], z01[i], z10[i], z11[i]), mv[i]);
         }
+    }
+    if (peak_partial) {
+        __shared__ float sh_peak[NT / 64];
+        peak = block_max_nan(peak, sh_peak);
+        if (threadIdx.x == 0) peak_partial[(long)b * gridDim.x + blockIdx.x] = peak;
     }
 }
 
@@ -187,25 +229,6 @@ __global__ __launch_bounds__(NT) void capture_sample_kernel(const float* __restr
 // ---------------------------------------------------------------------------------------
 constexpr int POST_MAX_CHUNKS = 256;      // partial maxima per image
 constexpr int POST_PX_PER_CHUNK = 4096;
-
-// torch.max's ordering: a NaN wins and then stays.
-__device__ __forceinline__ float max_nan(float m, float e) { return (e > m || e != e) ? e : m; }
-
-__device__ __forceinline__ float exposed(float ic, float off005, float g) {
-    return __fadd_rn(__fadd_rn(ic, off005), __fmul_rn(g, 0.005f));
-}
-
-__device__ __forceinline__ float block_max_nan(float m, float* sh) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = max_nan(m, __shfl_xor(m, o, 64));
-    const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) sh[wave] = m;
-    __syncthreads();
-    float r = sh[0];
-#pragma unroll
-    for (int w = 1; w < NT / 64; ++w) r = max_nan(r, sh[w]);
-    return r;
-}
 
 static inline int post_chunks(long HW) {
     const long n = (HW + POST_PX_PER_CHUNK - 1) / POST_PX_PER_CHUNK;
@@ -256,14 +279,14 @@ template <int VEC>
 __global__ __launch_bounds__(NT) void capture_sensor_kernel(const float* __restrict__ Ic, const float* __restrict__ offset,
                                                             const float* __restrict__ gauss,
                                                             const float* __restrict__ scale,
-                                                            const uint8_t* __restrict__ mask_u8,
-                                                            const float* __restrict__ partial, long HW, long span,
-                                                            float* __restrict__ Ic_scaled, float* __restrict__ Ic_mask) {
+                                                            uint8_t* mask_u8,
+                                                            const float* __restrict__ partial, int nparts, long HW,
+                                                            long span, float* __restrict__ Ic_scaled,
+                                                            float* __restrict__ Ic_mask, int rezero) {
     __shared__ float sh[NT / 64];
     const int b = blockIdx.y;
-    const int chunks = gridDim.x;
     float m = -INFINITY;
-    for (int c = threadIdx.x; c < chunks; c += NT) m = max_nan(m, partial[(long)b * chunks + c]);
+    for (int c = threadIdx.x; c < nparts; c += NT) m = max_nan(m, partial[(long)b * nparts + c]);
     const float peak = block_max_nan(m, sh);
     const float off005 = __fmul_rn(offset[b], 0.05f);
     const float gain = __fadd_rn(__fmul_rn(scale[b], 0.3f), 0.7f);
@@ -271,14 +294,17 @@ __global__ __launch_bounds__(NT) void capture_sensor_kernel(const float* __restr
     const long hi = lo + span < HW ? lo + span : HW;
     const float* ic = Ic + (long)b * HW;
     const float* g = gauss + (long)b * HW;
-    const uint8_t* mk = mask_u8 + (long)b * HW;
+    uint8_t* mk = mask_u8 + (long)b * HW;
     float* so = Ic_scaled + (long)b * HW;
     float* mo = Ic_mask + (long)b * HW;
+    // rezero: this kernel is the last reader of the visibility mask and hands it back cleared (every byte
+    // is read and then cleared by the same lane), so the caller's next capture needs no clear
     if (VEC == 4) {
         for (long p = lo + 4L * threadIdx.x; p < hi; p += 4L * NT) {
             const float4 a = *reinterpret_cast<const float4*>(ic + p);
             const float4 n = *reinterpret_cast<const float4*>(g + p);
             const uchar4 v = *reinterpret_cast<const uchar4*>(mk + p);
+            if (rezero) *reinterpret_cast<uchar4*>(mk + p) = make_uchar4(0, 0, 0, 0);
             float4 s, w;
             sensor_px(a.x, off005, n.x, peak, gain, (float)v.x, s.x, w.x);
             sensor_px(a.y, off005, n.y, peak, gain, (float)v.y, s.y, w.y);
@@ -288,8 +314,11 @@ __global__ __launch_bounds__(NT) void capture_sensor_kernel(const float* __restr
             *reinterpret_cast<float4*>(mo + p) = w;
         }
     } else {
-        for (long p = lo + threadIdx.x; p < hi; p += NT)
-            sensor_px(ic[p], off005, g[p], peak, gain, (float)mk[p], so[p], mo[p]);
+        for (long p = lo + threadIdx.x; p < hi; p += NT) {
+            const float v = (float)mk[p];
+            if (rezero) mk[p] = 0;
+            sensor_px(ic[p], off005, g[p], peak, gain, v, so[p], mo[p]);
+        }
     }
 }
 
@@ -422,45 +451,72 @@ extern "C" int fc3d_reflectance_fwd(void* stream, const float* I, int64_t i_sb, 
     return FC3D_OK;
 }
 
-extern "C" int fc3d_capture_warp_fwd(void* stream, const float* Ip, const float* z_p, const float* z_c,
-                                     const float* ray_x, const float* ray_y, const float* T_p2c, const float* T_c2p,
-                                     int B, int H, int W, float* Ic_masked, float* xyz_cview, uint8_t* mask_u8,
-                                     int mask_is_clear, float* grid_p2c, float* grid_c2p) {
+// forward warp + splat, then inverse warp.  pose != NULL: the transforms are outputs of the first launch.
+// peak_partial != NULL: the inverse warp also leaves cdiv(H*W, 512) partial maxima of the exposed image per sample.
+static int capture_warp_launch(hipStream_t s, const float* Ip, const float* z_p, const float* z_c, const float* ray_x,
+                               const float* ray_y, float* T_p2c, float* T_c2p, const float* pose, const float* K,
+                               int64_t k_sb, int B, int H, int W, float* Ic_masked, float* xyz_cview, uint8_t* mask_u8,
+                               int mask_is_clear, float* grid_p2c, float* grid_c2p, const float* offset,
+                               const float* gauss, float* peak_partial) {
     if (!Ip || !z_p || !z_c || !ray_x || !ray_y || !T_p2c || !T_c2p || !Ic_masked || !xyz_cview || !mask_u8)
         return FC3D_EINVAL;
+    if (peak_partial && (!offset || !gauss)) return FC3D_EINVAL;
     if (int e = check_img(B, H, W)) return e;
     if ((long)H * W >= (1L << 29)) return FC3D_ERANGE;   // per-image byte offsets of the taps are 32-bit
     if ((reinterpret_cast<uintptr_t>(grid_p2c) & 7u) || (reinterpret_cast<uintptr_t>(grid_c2p) & 7u)) return FC3D_EALIGN;
-    hipStream_t s = (hipStream_t)stream;
     dim3 g(cdiv((long)H * W, PX_PER_BLOCK), B), gp(cdiv((long)H * W, NT * CPX), B), blk(NT);
     if (!mask_is_clear) {
         if (int e = zero_fill(s, mask_u8, (size_t)B * H * W)) return e;
     }
     const bool lds = W + H <= RAY_LDS_MAX;
     const size_t nlds = lds ? (size_t)(W + H) * sizeof(float) : 0;
-#define SAMPLE_ARGS z_c, ray_x, ray_y, T_c2p, Ip, z_p, (const uint8_t*)mask_u8, H, W, grid_c2p, Ic_masked, xyz_cview
-#define SAMPLE_LAUNCH(FMA)                                                                                     \
+    const PoseArgs pa = {pose, K, (long)k_sb, T_p2c, T_c2p, nullptr};
+#define PROJECT_ARGS z_p, ray_x, ray_y, (const float*)T_p2c, H, W, grid_p2c, mask_u8, pa
+#define SAMPLE_ARGS z_c, ray_x, ray_y, (const float*)T_c2p, Ip, z_p, (const uint8_t*)mask_u8, H, W, grid_c2p, Ic_masked, xyz_cview, offset, gauss, peak_partial
+#define WARP_LAUNCH(FMA)                                                                                       \
     do {                                                                                                       \
+        if (pose) FC3D_LAUNCH("capture_project_splat", (capture_project_kernel<FMA, true>), gp, blk, 0, s, PROJECT_ARGS); \
+        else FC3D_LAUNCH("capture_project_splat", (capture_project_kernel<FMA, false>), gp, blk, 0, s, PROJECT_ARGS); \
         if (lds) FC3D_LAUNCH("capture_sample", (capture_sample_kernel<FMA, true>), g, blk, nlds, s, SAMPLE_ARGS); \
         else FC3D_LAUNCH("capture_sample", (capture_sample_kernel<FMA, false>), g, blk, 0, s, SAMPLE_ARGS);    \
     } while (0)
-    if (use_fma(H, W)) {
-        FC3D_LAUNCH("capture_project_splat", capture_project_kernel<true>, gp, blk, 0, s, z_p, ray_x, ray_y, T_p2c, H, W,
-                    grid_p2c, mask_u8);
-        SAMPLE_LAUNCH(true);
-    } else {
-        FC3D_LAUNCH("capture_project_splat", capture_project_kernel<false>, gp, blk, 0, s, z_p, ray_x, ray_y, T_p2c, H, W,
-                    grid_p2c, mask_u8);
-        SAMPLE_LAUNCH(false);
-    }
-#undef SAMPLE_LAUNCH
+    if (use_fma(H, W)) WARP_LAUNCH(true);
+    else WARP_LAUNCH(false);
+#undef WARP_LAUNCH
 #undef SAMPLE_ARGS
+#undef PROJECT_ARGS
     return FC3D_OK;
+}
+
+extern "C" int fc3d_capture_warp_fwd(void* stream, const float* Ip, const float* z_p, const float* z_c,
+                                     const float* ray_x, const float* ray_y, const float* T_p2c, const float* T_c2p,
+                                     int B, int H, int W, float* Ic_masked, float* xyz_cview, uint8_t* mask_u8,
+                                     int mask_is_clear, float* grid_p2c, float* grid_c2p) {
+    return capture_warp_launch((hipStream_t)stream, Ip, z_p, z_c, ray_x, ray_y, const_cast<float*>(T_p2c),
+                               const_cast<float*>(T_c2p), nullptr, nullptr, 0, B, H, W, Ic_masked, xyz_cview, mask_u8,
+                               mask_is_clear, grid_p2c, grid_c2p, nullptr, nullptr, nullptr);
 }
 
 extern "C" size_t fc3d_capture_post_workspace(int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0) return 0;
     return (size_t)B * post_chunks((long)H * W) * sizeof(float);
+}
+
+static int sensor_launch(hipStream_t s, const float* Ic, const float* offset, const float* gauss, const float* scale,
+                         uint8_t* mask_u8, int B, long HW, const float* partial, int nparts, float* Ic_scaled,
+                         float* Ic_mask, int rezero) {
+    const int chunks = post_chunks(HW);
+    const long span = post_span(HW, chunks);
+    const bool vec = HW % 4 == 0 && aligned16(Ic) && aligned16(gauss) && aligned16(Ic_scaled) && aligned16(Ic_mask) &&
+                     aligned4(mask_u8);
+    dim3 g(chunks, B), blk(NT);
+    if (vec)
+        FC3D_LAUNCH("capture_sensor", capture_sensor_kernel<4>, g, blk, 0, s, Ic, offset, gauss, scale, mask_u8, partial,
+                    nparts, HW, span, Ic_scaled, Ic_mask, rezero);
+    else
+        FC3D_LAUNCH("capture_sensor", capture_sensor_kernel<1>, g, blk, 0, s, Ic, offset, gauss, scale, mask_u8, partial,
+                    nparts, HW, span, Ic_scaled, Ic_mask, rezero);
+    return FC3D_OK;
 }
 
 extern "C" int fc3d_capture_post(void* stream, const float* Ic, const float* offset, const float* gauss,
@@ -473,18 +529,35 @@ extern "C" int fc3d_capture_post(void* stream, const float* Ic, const float* off
     const long HW = (long)H * W;
     const int chunks = post_chunks(HW);
     const long span = post_span(HW, chunks);
-    const bool vec = HW % 4 == 0 && aligned16(Ic) && aligned16(gauss) && aligned16(Ic_scaled) && aligned16(Ic_mask) &&
-                     aligned4(mask_u8);
+    const bool vec = HW % 4 == 0 && aligned16(Ic) && aligned16(gauss);
     float* partial = (float*)workspace;
     dim3 g(chunks, B), blk(NT);
-    if (vec) {
-        FC3D_LAUNCH("capture_peak", capture_peak_kernel<4>, g, blk, 0, s, Ic, offset, gauss, HW, span, partial);
-        FC3D_LAUNCH("capture_sensor", capture_sensor_kernel<4>, g, blk, 0, s, Ic, offset, gauss, scale, mask_u8,
-                    (const float*)partial, HW, span, Ic_scaled, Ic_mask);
-    } else {
-        FC3D_LAUNCH("capture_peak", capture_peak_kernel<1>, g, blk, 0, s, Ic, offset, gauss, HW, span, partial);
-        FC3D_LAUNCH("capture_sensor", capture_sensor_kernel<1>, g, blk, 0, s, Ic, offset, gauss, scale, mask_u8,
-                    (const float*)partial, HW, span, Ic_scaled, Ic_mask);
-    }
-    return FC3D_OK;
+    if (vec) FC3D_LAUNCH("capture_peak", capture_peak_kernel<4>, g, blk, 0, s, Ic, offset, gauss, HW, span, partial);
+    else FC3D_LAUNCH("capture_peak", capture_peak_kernel<1>, g, blk, 0, s, Ic, offset, gauss, HW, span, partial);
+    return sensor_launch(s, Ic, offset, gauss, scale, const_cast<uint8_t*>(mask_u8), B, HW, partial, chunks, Ic_scaled,
+                         Ic_mask, 0);
+}
+
+extern "C" size_t fc3d_capture_fwd_workspace(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    return ((size_t)B * 32 + (size_t)B * cdiv((long)H * W, PX_PER_BLOCK)) * sizeof(float);
+}
+
+extern "C" int fc3d_capture_fwd(void* stream, const float* Ip, const float* z_p, const float* z_c, const float* ray_x,
+                                const float* ray_y, const float* pose, const float* K, int64_t k_sb, const float* offset,
+                                const float* gauss, const float* scale, int B, int H, int W, float* Ic_masked,
+                                float* xyz_cview, float* Ic_scaled, float* Ic_mask, uint8_t* mask_u8, int mask_is_clear,
+                                int mask_rezero, void* workspace, float* grid_p2c, float* grid_c2p) {
+    if (!pose || !K || !offset || !gauss || !scale || !Ic_scaled || !Ic_mask || !workspace) return FC3D_EINVAL;
+    if (!aligned4(workspace)) return FC3D_EALIGN;
+    if (B <= 0 || H <= 0 || W <= 0) return FC3D_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    float* T_p2c = (float*)workspace;
+    float* T_c2p = T_p2c + (size_t)B * 16;
+    float* partial = T_c2p + (size_t)B * 16;
+    if (int e = capture_warp_launch(s, Ip, z_p, z_c, ray_x, ray_y, T_p2c, T_c2p, pose, K, k_sb, B, H, W, Ic_masked,
+                                    xyz_cview, mask_u8, mask_is_clear, grid_p2c, grid_c2p, offset, gauss, partial))
+        return e;
+    return sensor_launch(s, Ic_masked, offset, gauss, scale, mask_u8, B, (long)H * W, partial,
+                         cdiv((long)H * W, PX_PER_BLOCK), Ic_scaled, Ic_mask, mask_rezero);
 }

@@ -106,68 +106,6 @@ __global__ void pose_transforms_kernel(const float* __restrict__ pose, const flo
     }
 }
 
-// invert4 spread over the lanes of one wavefront: lane r*8 + j (upper half: a copy of the lower)
-// holds tableau entry m[r][j].  Every entry sees the operations invert4 applies to it, in the same
-// order, so the rounded inverse is the same; a lane needs one double instead of thirty-two, which
-// lets a streaming kernel invert its sample's pose on the side without giving up resident wavefronts.
-__device__ __forceinline__ double invert4_lanes(const float* __restrict__ a, int lane) {
-    const int l = lane & 31, r = l >> 3, j = l & 7;
-    double m = j < 4 ? (double)a[r * 4 + j] : (j - 4 == r ? 1.0 : 0.0);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-#pragma unroll
-        for (int r2 = c + 1; r2 < 4; ++r2) {        // the largest |m[r][c]|, r >= c, ends up in row c (first one on ties)
-            const double pc = __shfl(m, c * 8 + c, 64), pr = __shfl(m, r2 * 8 + c, 64);
-            const int partner = (r == c ? r2 : (r == r2 ? c : r)) * 8 + j;
-            const double other = __shfl(m, partner, 64);
-            if (fabs(pr) > fabs(pc)) m = other;
-        }
-        const double d = 1.0 / __shfl(m, c * 8 + c, 64);
-        if (r == c) m *= d;
-        const double f = __shfl(m, r * 8 + c, 64);
-        const double mc = __shfl(m, c * 8 + j, 64);
-        if (r != c) m -= f * mc;
-    }
-    return m;
-}
-
-// Element (i, j) = lane & 15 of K*A, the 4x4 product as torch's small-matrix loop rounds it
-// (intrinsics_times), with A's element (k, j) supplied by the caller's accessor.
-template <typename Acol>
-__device__ __forceinline__ float intrinsics_times_lane(const float* __restrict__ K, int i, Acol a_kj) {
-    float s = __fmul_rn(K[i * 4 + 0], a_kj(0));
-    s = __fadd_rn(s, __fmul_rn(K[i * 4 + 1], a_kj(1)));
-    s = __fadd_rn(s, __fmul_rn(K[i * 4 + 2], a_kj(2)));
-    s = __fadd_rn(s, __fmul_rn(K[i * 4 + 3], a_kj(3)));
-    return s;
-}
-
-// What pose_transforms_kernel computes for one sample, by one wavefront, on the side of another kernel.
-struct PoseArgs {
-    const float* pose;      // [B][16]
-    const float* K;         // K[b*k_sb + 4*i + j]
-    long k_sb;
-    float* t_fwd;           // [B][16] K*pose
-    float* t_inv;           // [B][16] K*inverse(pose)
-    float* inv;             // [B][16] inverse(pose), may be null
-};
-__device__ __forceinline__ void pose_outputs_wave(const PoseArgs& pa, int b, int lane, float t_fwd_e) {
-    const float* A = pa.pose + (long)b * 16;
-    const float* Kb = pa.K + (long)b * pa.k_sb;
-    const int e = lane & 15, i = e >> 2, j = e & 3;
-    const double m = invert4_lanes(A, lane);
-    float af[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) af[k] = (float)__shfl(m, k * 8 + 4 + j, 64);
-    const float own = (float)__shfl(m, i * 8 + 4 + j, 64);
-    const float ti = intrinsics_times_lane(Kb, i, [&](int k) { return af[k]; });
-    if (lane < 16) {
-        pa.t_fwd[(long)b * 16 + e] = t_fwd_e;
-        pa.t_inv[(long)b * 16 + e] = ti;
-        if (pa.inv) pa.inv[(long)b * 16 + e] = own;
-    }
-}
-
 // ---------------------------------------------------------------------------------------
 // projection
 // ---------------------------------------------------------------------------------------
@@ -215,20 +153,7 @@ __global__ __launch_bounds__(NT) void project_kernel(const float* __restrict__ c
     // after the coordinate loads were issued: the few words of K and pose arrive under their latency
     float T[16];
     if (POSE) {
-        // two loads per lane (element lane & 15 of either matrix), the row of K and the column of
-        // pose a lane needs then come from its neighbours
-        const int lane = threadIdx.x & 63, e = lane & 15, i = e >> 2, j = e & 3;
-        const float kv = pa.K[(long)b * pa.k_sb + e], av = pa.pose[(long)b * 16 + e];
-        float kr[4], ac[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            kr[k] = __shfl(kv, i * 4 + k, 64);
-            ac[k] = __shfl(av, k * 4 + j, 64);
-        }
-        const float te = intrinsics_times_lane(kr, 0, [&](int k) { return ac[k]; });
-#pragma unroll
-        for (int k = 0; k < 16; ++k) T[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(te), k));
-        if (blockIdx.x == 0 && threadIdx.x < 64) pose_outputs_wave(pa, b, lane, te);
+        form_transform(pa, b, T);
     } else {
 #pragma unroll
         for (int k = 0; k < 16; ++k) T[k] = Tm[(long)b * 16 + k];

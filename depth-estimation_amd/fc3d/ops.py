@@ -895,6 +895,45 @@ def capture_post(Ic, offset, gauss, scale, mask_u8):
     return scaled, valid
 
 
+def capture_fwd(Ip, z_p, z_c, ray_x, ray_y, pose, K, offset, gauss, scale, want_grids=False):
+    """capture_warp + capture_post from the pose and the intrinsic matrix in three launches (forward warp
+    that forms K*pose itself, inverse warp that also finds the sensor model's peak, sensor model):
+    (Ic_masked, xyz_cview, Ic_scaled, Ic_mask[, grid_p2c, grid_c2p]), bit-identical to the two-step form;
+    no gradient.  The visibility mask is a buffer that the sensor kernel hands back cleared."""
+    dev = _need_gpu(Ip, z_p, z_c, ray_x, ray_y, pose, K, offset, gauss, scale)
+    B, H, W = z_p.shape[0], z_p.shape[1], z_p.shape[2]
+    if ray_x.numel() != W or ray_y.numel() != H or tuple(pose.shape) != (B, 4, 4):
+        raise ValueError("ray table or pose do not match the depth maps")
+    if offset.numel() != B or scale.numel() != B:
+        raise ValueError("offset and scale hold one value per sample")
+    Ip, z_p, z_c, gauss = (_plane(t.detach(), B, H, W, n) for t, n in ((Ip, "Ip"), (z_p, "z_p"), (z_c, "z_c"),
+                                                                       (gauss, "gauss")))
+    K, k_sb = _intrinsics_args(K, B)
+    Ic = torch.empty((B, H, W, 1), dtype=torch.float32, device=dev)
+    xyz = torch.empty((B, H, W, 3), dtype=torch.float32, device=dev)
+    scaled = torch.empty((B, H, W, 1), dtype=torch.float32, device=dev)
+    valid = torch.empty((B, H, W, 1), dtype=torch.float32, device=dev)
+    gp = torch.empty((B, H, W, 2), dtype=torch.float32, device=dev) if want_grids else None
+    gc = torch.empty((B, H, W, 2), dtype=torch.float32, device=dev) if want_grids else None
+    ws = torch.empty(_lib.fc3d_capture_fwd_workspace(B, H, W) // 4, dtype=torch.float32, device=dev)
+    with _on_device(dev):
+        s = _stream()
+        key, mask = _pooled_zero_mask(B, H, W, dev, s, torch.cuda.is_current_stream_capturing())
+        pooled = mask is not None
+        if not pooled:
+            mask = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+        status = _lib.fc3d_capture_fwd(s, Ip.data_ptr(), z_p.data_ptr(), z_c.data_ptr(), _dense(ray_x).data_ptr(),
+                                       _dense(ray_y).data_ptr(), _dense(pose.detach()).data_ptr(), K.data_ptr(), k_sb,
+                                       _dense(offset).data_ptr(), gauss.data_ptr(), _dense(scale).data_ptr(), B, H, W,
+                                       Ic.data_ptr(), xyz.data_ptr(), scaled.data_ptr(), valid.data_ptr(),
+                                       mask.data_ptr(), int(pooled), int(pooled), ws.data_ptr(),
+                                       gp.data_ptr() if want_grids else None, gc.data_ptr() if want_grids else None)
+        if status != 0 and pooled:
+            _zero_masks.pop(key, None)
+        _check(status, "fc3d_capture_fwd")
+    return (Ic, xyz, scaled, valid, gp, gc) if want_grids else (Ic, xyz, scaled, valid)
+
+
 def box_filter(img: torch.Tensor, k: int, mode: str = "mean", c: float = 0.0) -> torch.Tensor:
     """k x k zero-padded box mean of a one-channel [B,H,W,1] image ("mean"), the image divided by
     (mean + c) ("local_norm"), or the erosion mean > 0.999 of a 0/1 mask ("erode"); no gradient."""

@@ -358,6 +358,22 @@ size_t fc3d_capture_post_workspace(int B, int H, int W);
 int fc3d_capture_post(void *stream, const float *Ic, const float *offset, const float *gauss, const float *scale,
                       const uint8_t *mask_u8, int B, int H, int W, float *Ic_scaled, float *Ic_mask, void *workspace);
 
+/* The capture simulator after codePattern in three launches (train_pytorch.py:94-104, :118): the
+ * forward warp forms K*pose itself (see fc3d_warp_p2c_pose_fwd), the inverse warp finds the partial
+ * maxima of the exposed image while it writes Ic (no pass of its own for the sensor model's peak),
+ * the sensor model, as the mask's last reader, hands it back cleared when mask_rezero != 0.
+ * Results are bit-identical to fc3d_pose_transforms + fc3d_capture_warp_fwd + fc3d_capture_post.
+ * workspace: fc3d_capture_fwd_workspace() bytes (the two transforms and the partial maxima);
+ * grid_p2c / grid_c2p may be NULL.  No counterpart as one function in the reference: it is the
+ * body of forward_model between codePattern and the crops.                                    */
+size_t fc3d_capture_fwd_workspace(int B, int H, int W);
+int fc3d_capture_fwd(void *stream, const float *Ip, const float *z_p, const float *z_c,
+                     const float *ray_x, const float *ray_y, const float *pose, const float *K, int64_t k_sb,
+                     const float *offset, const float *gauss, const float *scale, int B, int H, int W,
+                     float *Ic_masked, float *xyz_cview, float *Ic_scaled, float *Ic_mask,
+                     uint8_t *mask_u8, int mask_is_clear, int mask_rezero, void *workspace,
+                     float *grid_p2c, float *grid_c2p);
+
 /* k x k box mean with zero padding, F.avg_pool2d(x, k, stride=1, padding=k/2) on one-channel
  * images [B][H][W] (k odd, <= 33), and its two uses in the training loop:
  *   mode 0  out = mean

@@ -218,6 +218,26 @@ def test_capture_kernels_match_composed_operators(env, monkeypatch, B, H, W):
     assert torch.equal(scaled.cpu(), Is)
     assert torch.equal(valid.cpu(), Im)
 
+    # the three-launch form (pose formed in the forward warp, the sensor's peak found by the inverse warp, the
+    # mask handed back cleared by the sensor kernel): bit for bit the steps above, call after call; a NaN in
+    # the noise must reach the peak the way torch.max lets it
+    Kmat = G._intrinsics_for(B, z_p.device)
+    for rep in range(3):
+        gau_r = gau.copy()
+        if rep == 2:
+            gau_r[0, H // 2, W // 3, 0] = np.nan
+        s2, v2 = ops.capture_post(Ic, d(off), d(gau_r), d(sca), mask)
+        got = ops.capture_fwd(Ip, z_p, z_c, rx, ry, pose, Kmat, d(off), d(gau_r), d(sca), want_grids=(rep == 1))
+        assert torch.equal(got[0], Ic) and torch.equal(got[1], xyz), rep
+        assert torch.equal(got[2], s2, ) or (rep == 2 and torch.equal(torch.isnan(got[2]), torch.isnan(s2))), rep
+        assert torch.equal(got[3], v2), rep
+        if rep == 1:
+            assert torch.equal(got[4], gp) and torch.equal(got[5], gc)
+        if rep == 2:
+            assert bool(torch.isnan(got[2][0]).all()) and not bool(torch.isnan(got[2][1:]).any())
+    for m in ops._zero_masks.values():
+        assert int(m.count_nonzero()) == 0
+
 
 def test_capture_kernels_vs_reference_fixture(env, golden):
     """Shading, local normalisation and erosion kernels against outputs of the reference's
