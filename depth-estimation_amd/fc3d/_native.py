@@ -32,6 +32,8 @@ SIGNATURES = {
                                       LayerGrid, P, P, P, POINTER(c_int)]),
     "fc3d_code_pattern_shaded_fwd": (c_int, [P, P, I64, I64, I64, P, c_int, c_int, c_int, LayerGrid, P, P, P,
                                              POINTER(c_int)]),
+    "fc3d_code_pattern_shaded_conv_fwd": (c_int, [P, P, I64, I64, I64, P, P, c_int, c_int, c_int, c_int, c_int, LayerGrid,
+                                                  P, P, P, POINTER(c_int)]),
     "fc3d_code_pattern_norm": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P]),
     "fc3d_code_pattern_bwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
     "fc3d_code_pattern_bwd_dot_supported": (c_int, [c_int, c_int, c_int]),

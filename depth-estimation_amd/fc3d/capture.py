@@ -161,10 +161,11 @@ def forward_model(z_p, z_c, pose_p2c, n_layers=21, is_conv_psf=True, crop=None, 
         from . import ops
         rx, ry = G._separable_rays(W, H, dev)
         Ip0 = Ip if Ip.shape[3] == 1 else Ip[..., 0:1]          # codePattern reads channel 0 only
-        if is_conv_psf:
+        psf = O._device_psfs(dev) if is_conv_psf else None
+        if is_conv_psf and not (ops.code_pattern_shaded_supported(psf) and psf.shape[0] == n_layers):
             Ip_coded = O.codePattern(ops.reflectance(Ip0, z_p), z_p, is_conv_psf=True, n_layers=n_layers)
-        else:                                                   # the training mode: shading and gating in one pass
-            Ip_coded = ops.code_pattern_shaded(Ip0, z_p, O._layer_grid(n_layers))
+        else:          # shading folded into the PSF kernel (3x3..7x7) or, in the training mode, into the gating pass
+            Ip_coded = ops.code_pattern_shaded(Ip0, z_p, O._layer_grid(n_layers), psf)
         # three launches: forward warp (forms K*pose itself), inverse warp (+ the sensor's peak), sensor model
         Ic, xyz_cView, Ic_scaled, Ic_mask = ops.capture_fwd(Ip_coded, z_p, z_c, rx, ry, pose_p2c, K, noise["offset"],
                                                             noise["gauss"], noise["scale"])

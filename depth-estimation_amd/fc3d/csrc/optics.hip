@@ -476,6 +476,9 @@ __device__ __forceinline__ void lds_read4(const float* p, float (&dst)[N]) {
 // offset; when an output row is complete the K column sums are handed sideways Horner fashion,
 // one shift per column step.
 // ---------------------------------------------------------------------------------------
+#ifndef FC3D_SHADE_WAVES
+#define FC3D_SHADE_WAVES 5
+#endif
 template <int K>
 struct Roll {
     static constexpr int PAD = (K - 1) / 2;
@@ -483,6 +486,7 @@ struct Roll {
     static constexpr int KK = K * K;
     static constexpr int KKP = (KK + 3) & ~3;    // one layer's PSF, padded to whole float4s
     static constexpr int FWD_WAVES = K <= 5 ? 6 : 3;   // wavefronts per SIMD the forward kernel is compiled for
+    static constexpr int FWD_WAVES_SHADE = K <= 5 ? FC3D_SHADE_WAVES : 3;   // ... with the shading folded in (a depth value per pattern row more)
 };
 
 // lane i receives lane i-1's value (lane 0: zero) / lane i+1's value (lane 63: zero)
@@ -668,8 +672,13 @@ __global__ __launch_bounds__(NT) void code_pattern_bwd_max_kernel(
 // (K <= 5: six wavefronts per SIMD -- the kernel waits on memory more than it computes, and one
 // more resident wavefront is worth the couple of spilled registers the limit costs; the 7x7
 // window and weights need about 100 more registers and are left to the compiler's own choice)
-template <int K, int R>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(Roll<K>::FWD_WAVES, Roll<K>::FWD_WAVES)))
+// SHADE: the pattern is first multiplied by the surface-slope shading of the same depth map
+// (withReflectance, utils_pytorch.py:251-280, then codePattern: train_pytorch.py:91-94), so that the shaded
+// pattern never goes through memory: the depth is loaded for every pattern row of the strip plus the row
+// below, the right neighbour comes from the next lane (lane 63 loads its own).
+template <int K, int R, bool SHADE = false>
+__global__ __launch_bounds__(NT)
+__attribute__((amdgpu_waves_per_eu(SHADE ? Roll<K>::FWD_WAVES_SHADE : Roll<K>::FWD_WAVES, SHADE ? Roll<K>::FWD_WAVES_SHADE : Roll<K>::FWD_WAVES)))
 void code_pattern_fwd_roll_kernel(
     const float* __restrict__ pat0, long sb, long sh, long sw, const float* __restrict__ z,
     const float* __restrict__ psf, int H, int W, int nstrips, fc3d_layer_grid lg, float* __restrict__ raw,
@@ -700,8 +709,27 @@ void code_pattern_fwd_roll_kernel(
     float pv[NR], zv[R];
 #pragma unroll
     for (int r = 0; r < NR; ++r) pv[r] = ld_at(pimg, (unsigned)min(max(y0 - PAD + r, 0), H - 1) * (unsigned)sh + pcol);
+    if (!SHADE) {
 #pragma unroll
-    for (int o = 0; o < R; ++o) zv[o] = ld_at(zimg, (unsigned)(min(y0 + o, H - 1) * W + xc));
+        for (int o = 0; o < R; ++o) zv[o] = ld_at(zimg, (unsigned)(min(y0 + o, H - 1) * W + xc));
+    } else {
+        float za[NR + 1], zr63[NR];       // depth of every pattern row and the one below; lane 63's right neighbours
+#pragma unroll
+        for (int r = 0; r <= NR; ++r) za[r] = ld_at(zimg, (unsigned)(min(max(y0 - PAD + r, 0), H - 1) * W + xc));
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+            zr63[r] = lane == 63 ? ld_at(zimg, (unsigned)(min(max(y0 - PAD + r, 0), H - 1) * W + min(xc + 1, W - 1))) : 0.0f;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int y = y0 - PAD + r;
+            float zright = from_lane_above(za[r]);
+            if (lane == 63) zright = zr63[r];
+            // rows and columns outside the image are zero padding below, whatever the shading says there
+            pv[r] = shade(pv[r], za[r], zright, za[r + 1], x + 1 < W, y + 1 < H);
+        }
+#pragma unroll
+        for (int o = 0; o < R; ++o) zv[o] = za[o + PAD];
+    }
     const LayerFast lfast = layer_fast_setup(lg);
     stage_psf_stack<K>(smem, psf, lg.n_layers);   // after the loads above were issued: the latencies overlap
     __syncthreads();
@@ -1513,6 +1541,37 @@ extern "C" int fc3d_code_pattern_shaded_fwd(void* stream, const float* pat0, int
     if (fvec) FC3D_LAUNCH("code_pattern_shaded_fwd", (code_pattern_flat_fwd_kernel<true, true>), gf, blk, 0, s, pat0, (long)pat_sb, (long)pat_sh, (long)pat_sw, z, H, W, grid, raw_out, layer_u8, (unsigned long long*)tilekey_u64);
     else FC3D_LAUNCH("code_pattern_shaded_fwd", (code_pattern_flat_fwd_kernel<false, true>), gf, blk, 0, s, pat0, (long)pat_sb, (long)pat_sh, (long)pat_sw, z, H, W, grid, raw_out, layer_u8, (unsigned long long*)tilekey_u64);
     return FC3D_OK;
+}
+
+extern "C" int fc3d_code_pattern_shaded_conv_fwd(void* stream, const float* pat0, int64_t pat_sb, int64_t pat_sh,
+                                                int64_t pat_sw, const float* z, const float* psf, int B, int H, int W,
+                                                int Kh, int Kw, fc3d_layer_grid grid, float* raw_out, uint8_t* layer_u8,
+                                                uint64_t* tilekey_u64, int* keys_per_image) {
+    if (!pat0 || !z || !psf || !raw_out || !tilekey_u64 || !keys_per_image || B <= 0 || H <= 0 || W <= 0) return FC3D_EINVAL;
+    if (grid.n_layers <= 0 || grid.n_layers > 254) return FC3D_EINVAL;
+    if (Kh != Kw || (Kw != 3 && Kw != 5 && Kw != 7)) return FC3D_EINVAL;      // the rolling-row sizes
+    const long HW = (long)H * W;
+    if ((long)B * HW >= (1L << 31) || B > 65535 || HW >= (1L << 30)) return FC3D_ERANGE;
+    if (pat_sh < 0 || pat_sw < 0 || (long)(H - 1) * pat_sh + (long)(W - 1) * pat_sw >= (1L << 30)) return FC3D_ERANGE;
+    if (!aligned4(pat0) || !aligned4(z) || !aligned4(raw_out)) return FC3D_EALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 blk(NT);
+    constexpr int RR = kRollRows;
+#define FC3D_FWD_SHADE_CASE(KV)                                                                                  \
+    if (Kw == KV) {                                                                                              \
+        const size_t rlds = (size_t)grid.n_layers * Roll<KV>::KKP * sizeof(float);                               \
+        if (int e = allow_big_lds(code_pattern_fwd_roll_kernel<KV, RR, true>, rlds)) return e;                   \
+        const int nstrips = cdiv(W, Roll<KV>::SW);                                                               \
+        const dim3 gr(cdiv((long)nstrips * cdiv(H, RR), NT / 64), B);                                            \
+        *keys_per_image = (int)(gr.x * (NT / 64));                                                               \
+        FC3D_LAUNCH("code_pattern_shaded_fwd", (code_pattern_fwd_roll_kernel<KV, RR, true>), gr, blk, rlds, s,   \
+                    pat0, (long)pat_sb, (long)pat_sh, (long)pat_sw, z, psf, H, W, nstrips, grid, raw_out,        \
+                    layer_u8, (unsigned long long*)tilekey_u64);                                                 \
+        return FC3D_OK;                                                                                          \
+    }
+    FC3D_FWD_SHADE_CASE(3) FC3D_FWD_SHADE_CASE(5) FC3D_FWD_SHADE_CASE(7)
+#undef FC3D_FWD_SHADE_CASE
+    return FC3D_EINVAL;
 }
 
 extern "C" int fc3d_code_pattern_norm(void* stream, const float* raw, const uint64_t* tilekey_u64,

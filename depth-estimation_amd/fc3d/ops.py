@@ -810,11 +810,19 @@ def _plane(t: torch.Tensor, B: int, H: int, W: int, what: str) -> torch.Tensor:
     return _dense(t)
 
 
-def code_pattern_shaded(I: torch.Tensor, z: torch.Tensor, grid: LayerGrid) -> torch.Tensor:
-    """codePattern(withReflectance(I, z), z, is_conv_psf=False) in one streaming pass plus the
-    normalisation: the pattern path of the reference's training loop.  I [B or 1,H,W,1] (channel 0
-    of the pattern), z [B,H,W,1] -> [B,H,W,1]; no gradient."""
-    dev = _need_gpu(I, z)
+def code_pattern_shaded_supported(psf: torch.Tensor) -> bool:
+    """Can code_pattern_shaded fold the shading into the blur with this PSF stack?"""
+    return psf.dim() == 3 and psf.shape[1] == psf.shape[2] and int(psf.shape[1]) in (3, 5, 7)
+
+
+def code_pattern_shaded(I: torch.Tensor, z: torch.Tensor, grid: LayerGrid, psf: torch.Tensor | None = None) -> torch.Tensor:
+    """codePattern(withReflectance(I, z), z) in one pass plus the normalisation.  psf None:
+    is_conv_psf=False, the pattern path of the reference's training loop (one streaming pass);
+    psf [L,K,K] with K in (3, 5, 7): is_conv_psf=True, the shading folded into the rolling-row blur.
+    I [B or 1,H,W,1] (channel 0 of the pattern), z [B,H,W,1] -> [B,H,W,1]; no gradient."""
+    dev = _need_gpu(I, z, psf)
+    if psf is not None and (not code_pattern_shaded_supported(psf) or psf.shape[0] != grid.n_layers):
+        raise ValueError(f"no shaded blur for a PSF stack of shape {tuple(psf.shape)} with {grid.n_layers} layers")
     B, H, W = z.shape[0], z.shape[1], z.shape[2]
     if I.dim() != 4 or I.shape[3] != 1 or I.shape[0] not in (1, B) or tuple(I.shape[1:3]) != (H, W):
         raise ValueError(f"pattern of shape {tuple(I.shape)} does not match depth {tuple(z.shape)}")
@@ -828,9 +836,17 @@ def code_pattern_shaded(I: torch.Tensor, z: torch.Tensor, grid: LayerGrid) -> to
     nkeys = ctypes.c_int(0)
     with _on_device(dev):
         s = _stream()
-        _check(_lib.fc3d_code_pattern_shaded_fwd(s, I.data_ptr(), sb, I.stride(1), I.stride(2), zd.data_ptr(), B, H, W,
-                                                 grid, out.data_ptr(), None, keys.data_ptr(), ctypes.byref(nkeys)),
-               "fc3d_code_pattern_shaded_fwd")
+        if psf is None:
+            _check(_lib.fc3d_code_pattern_shaded_fwd(s, I.data_ptr(), sb, I.stride(1), I.stride(2), zd.data_ptr(), B, H, W,
+                                                     grid, out.data_ptr(), None, keys.data_ptr(), ctypes.byref(nkeys)),
+                   "fc3d_code_pattern_shaded_fwd")
+        else:
+            pd = _dense(psf)
+            _check(_lib.fc3d_code_pattern_shaded_conv_fwd(s, I.data_ptr(), sb, I.stride(1), I.stride(2), zd.data_ptr(),
+                                                          pd.data_ptr(), B, H, W, int(pd.shape[1]), int(pd.shape[2]),
+                                                          grid, out.data_ptr(), None, keys.data_ptr(),
+                                                          ctypes.byref(nkeys)),
+                   "fc3d_code_pattern_shaded_conv_fwd")
         _check(_lib.fc3d_code_pattern_norm(s, out.data_ptr(), keys.data_ptr(), nkeys.value, B, H, W, out.data_ptr(),
                                            mx.data_ptr(), am.data_ptr()), "fc3d_code_pattern_norm")
     return out

@@ -92,6 +92,15 @@ int fc3d_code_pattern_shaded_fwd(void *stream, const float *pat0, int64_t pat_sb
                                  uint8_t *layer_u8, uint64_t *tilekey_u64,
                                  int *keys_per_image /* HOST, out */);
 
+/* The same fusion with the blur (is_conv_psf=True): withReflectance (utils_pytorch.py:251-280) folded
+ * into the rolling-row forward kernel of fc3d_code_pattern_fwd, for square 3x3 / 5x5 / 7x7 PSFs
+ * (FC3D_EINVAL otherwise: shade with fc3d_reflectance_fwd, then fc3d_code_pattern_fwd).  Results are
+ * bit-identical to those two calls.  Followed by fc3d_code_pattern_norm like every forward.     */
+int fc3d_code_pattern_shaded_conv_fwd(void *stream, const float *pat0, int64_t pat_sb, int64_t pat_sh, int64_t pat_sw,
+                                      const float *z, const float *psf, int B, int H, int W, int Kh, int Kw,
+                                      fc3d_layer_grid grid, float *raw_out, uint8_t *layer_u8,
+                                      uint64_t *tilekey_u64, int *keys_per_image);
+
 /* Forward, second half: out = raw / (max + 1e-10) per image, in place allowed
  * (optics_pytorch.py:118-119).  Also unpacks max_out[B] and argmax_i32[B]
  * (flat y*W+x of the pixel that receives the max's gradient).                 */

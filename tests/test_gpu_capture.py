@@ -188,6 +188,17 @@ def test_capture_kernels_match_composed_operators(env, monkeypatch, B, H, W):
         # ... and fused with the no-blur codePattern (the training mode): identical to the two steps
         one = env["O"].codePattern(got, z_p, is_conv_psf=False, n_layers=21)
         assert torch.equal(ops.code_pattern_shaded(pat, z_p, env["O"]._layer_grid(21)), one)
+        # ... and folded into the blur for the PSF sizes of the rolling-row kernel
+        from fc3d import synth
+        keep = env["O"].PSFs_np
+        try:
+            for Kpsf in (3, 5, 7):
+                env["O"].PSFs_np = synth.make_psfs(21, Kpsf, "disc")
+                two = env["O"].codePattern(got, z_p, is_conv_psf=True, n_layers=21)
+                psf = env["O"]._device_psfs(z_p.device)
+                assert torch.equal(ops.code_pattern_shaded(pat, z_p, env["O"]._layer_grid(21), psf), two), Kpsf
+        finally:
+            env["O"].PSFs_np = keep
 
     # warp from the depth maps
     rays = G.pixel_to_ray_array(W, H)
