@@ -902,10 +902,13 @@ __global__ __launch_bounds__(NT) void code_pattern_flat_fwd_kernel(
 
 // g_pat0 = g / (max + 1e-10) where the pixel has a layer, 0 elsewhere, and one partial of sum(g*out)
 // per wavefront for the fix-up of the maximum's pixel (code_pattern_bwd_max_kernel, 1x1 footprint).
-template <bool VEC>
+// DOT: sum(g*out) is handed over as ndot partial sums per image (see the rolling-row backward): `out` is
+// not read, no partial is written, and the pixel that holds the maximum gets (g - S)/den.
+template <bool VEC, bool DOT = false>
 __global__ __launch_bounds__(NT) void code_pattern_flat_bwd_kernel(
     const float* __restrict__ g, const float* __restrict__ out, const uint8_t* __restrict__ layer_u8,
-    const float* __restrict__ max_in, unsigned HW, float* __restrict__ partial, float* __restrict__ g_pat0) {
+    const float* __restrict__ max_in, unsigned HW, float* __restrict__ partial, float* __restrict__ g_pat0,
+    const int* __restrict__ argmax_in, const float* __restrict__ dot_partial, int ndot) {
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const unsigned wave = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
@@ -916,6 +919,16 @@ __global__ __launch_bounds__(NT) void code_pattern_flat_bwd_kernel(
     float* gp = g_pat0 + (long)b * HW;
     const float rden = 1.0f / (max_in[b] + 1e-10f);
     float sgo = 0.0f;
+    unsigned am = 0xffffffffu;          // DOT: the maximum's pixel if this wavefront owns it, and S
+    float S = 0.0f;
+    if (DOT) {
+        const unsigned a = (unsigned)argmax_in[b];
+        if (a >= q0 && a < q0 + FLAT_WAVE_PX) {      // the same in every lane
+            for (int i = lane; i < ndot; i += 64) S += dot_partial[(long)b * ndot + i];
+            S = wave_sum(S);
+            am = a;
+        }
+    }
     if (VEC) {
         float4 gv[FLAT_GROUPS], ov[FLAT_GROUPS];
         uchar4 lv[FLAT_GROUPS];
@@ -923,15 +936,20 @@ __global__ __launch_bounds__(NT) void code_pattern_flat_bwd_kernel(
         for (int k = 0; k < FLAT_GROUPS; ++k) {
             const unsigned q = min(q0 + k * 256u + lane * 4u, HW - 4u);
             gv[k] = ld_at(reinterpret_cast<const float4*>(gi), q >> 2);
-            ov[k] = ld_at(reinterpret_cast<const float4*>(oi), q >> 2);
+            if (!DOT) ov[k] = ld_at(reinterpret_cast<const float4*>(oi), q >> 2);
             lv[k] = ld_at(reinterpret_cast<const uchar4*>(li), q >> 2);
         }
 #pragma unroll
         for (int k = 0; k < FLAT_GROUPS; ++k) {
             const unsigned q = q0 + k * 256u + lane * 4u;
             if (q >= HW) continue;
-            sgo = fmaf(gv[k].x, ov[k].x, sgo); sgo = fmaf(gv[k].y, ov[k].y, sgo);
-            sgo = fmaf(gv[k].z, ov[k].z, sgo); sgo = fmaf(gv[k].w, ov[k].w, sgo);
+            if (DOT) {
+                gv[k].x -= q == am ? S : 0.0f; gv[k].y -= q + 1 == am ? S : 0.0f;
+                gv[k].z -= q + 2 == am ? S : 0.0f; gv[k].w -= q + 3 == am ? S : 0.0f;
+            } else {
+                sgo = fmaf(gv[k].x, ov[k].x, sgo); sgo = fmaf(gv[k].y, ov[k].y, sgo);
+                sgo = fmaf(gv[k].z, ov[k].z, sgo); sgo = fmaf(gv[k].w, ov[k].w, sgo);
+            }
             float4 r;
             r.x = lv[k].x != 255 ? gv[k].x * rden : 0.0f; r.y = lv[k].y != 255 ? gv[k].y * rden : 0.0f;
             r.z = lv[k].z != 255 ? gv[k].z * rden : 0.0f; r.w = lv[k].w != 255 ? gv[k].w * rden : 0.0f;
@@ -941,13 +959,16 @@ __global__ __launch_bounds__(NT) void code_pattern_flat_bwd_kernel(
         for (int i = 0; i < 4 * FLAT_GROUPS; ++i) {
             const unsigned q = q0 + i * 64u + lane;
             if (q >= HW) break;
-            const float gq = gi[q];
-            sgo = fmaf(gq, oi[q], sgo);
+            float gq = gi[q];
+            if (DOT) gq -= q == am ? S : 0.0f;
+            else sgo = fmaf(gq, oi[q], sgo);
             gp[q] = li[q] != 255 ? gq * rden : 0.0f;
         }
     }
-    sgo = wave_sum(sgo);
-    if (lane == 0) partial[(long)b * (gridDim.x * (NT / 64)) + wave] = sgo;
+    if (!DOT) {
+        sgo = wave_sum(sgo);
+        if (lane == 0) partial[(long)b * (gridDim.x * (NT / 64)) + wave] = sgo;
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1610,8 +1631,8 @@ extern "C" int fc3d_code_pattern_bwd(void* stream, const float* g_out, const flo
     if (!conv_flag && HW < (1L << 30)) {
         const dim3 gf(cdiv(cdiv(HW, FLAT_WAVE_PX), NT / 64), B);
         const bool fvec = HW % 4 == 0 && HW >= 4 && aligned16(g_out) && aligned16(out) && aligned16(g_pat0) && aligned4(layer_u8);
-        if (fvec) FC3D_LAUNCH("code_pattern_bwd", code_pattern_flat_bwd_kernel<true>, gf, dim3(NT), 0, s, g_out, out, layer_u8, max_in, (unsigned)HW, partial, g_pat0);
-        else FC3D_LAUNCH("code_pattern_bwd", code_pattern_flat_bwd_kernel<false>, gf, dim3(NT), 0, s, g_out, out, layer_u8, max_in, (unsigned)HW, partial, g_pat0);
+        if (fvec) FC3D_LAUNCH("code_pattern_bwd", (code_pattern_flat_bwd_kernel<true, false>), gf, dim3(NT), 0, s, g_out, out, layer_u8, max_in, (unsigned)HW, partial, g_pat0, (const int*)nullptr, (const float*)nullptr, 0);
+        else FC3D_LAUNCH("code_pattern_bwd", (code_pattern_flat_bwd_kernel<false, false>), gf, dim3(NT), 0, s, g_out, out, layer_u8, max_in, (unsigned)HW, partial, g_pat0, (const int*)nullptr, (const float*)nullptr, 0);
         FC3D_LAUNCH("code_pattern_bwd_max", code_pattern_bwd_max_kernel, dim3(B), dim3(NT), 0, s, (const float*)partial,
                     (int)(gf.x * (NT / 64)), max_in, argmax_i32, layer_u8, (const float*)nullptr, H, W, 1, g_pat0);
         return FC3D_OK;
@@ -1660,20 +1681,27 @@ extern "C" int fc3d_code_pattern_bwd(void* stream, const float* g_out, const flo
 }
 
 extern "C" int fc3d_code_pattern_bwd_dot_supported(int Kh, int Kw, int conv_flag) {
-    return conv_flag && Kh == Kw && Kw >= 3 && Kw <= 33 && (Kw & 1);
+    return !conv_flag || (Kh == Kw && Kw >= 3 && Kw <= 33 && (Kw & 1));
 }
 
 extern "C" int fc3d_code_pattern_bwd_dot(void* stream, const float* g_out, const float* dot_partial, int n_partial,
                                          const uint8_t* layer_u8, const float* max_in, const int32_t* argmax_i32,
                                          const float* psf, int B, int H, int W, int L, int Kh, int Kw, int conv_flag,
                                          float* g_pat0) {
-    if (!g_out || !dot_partial || n_partial <= 0 || !layer_u8 || !max_in || !argmax_i32 || !psf || !g_pat0)
+    if (!g_out || !dot_partial || n_partial <= 0 || !layer_u8 || !max_in || !argmax_i32 || (conv_flag && !psf) || !g_pat0)
         return FC3D_EINVAL;
     if (B <= 0 || H <= 0 || W <= 0 || L <= 0 || L > 254) return FC3D_EINVAL;
     if (!fc3d_code_pattern_bwd_dot_supported(Kh, Kw, conv_flag)) return FC3D_EINVAL;
     const long HW = (long)H * W;
     if ((long)B * HW >= (1L << 31) || B > 65535 || HW >= (1L << 30)) return FC3D_ERANGE;
     hipStream_t s = (hipStream_t)stream;
+    if (!conv_flag) {       // is_conv_psf=False: the streaming kernel, 1x1 footprint
+        const dim3 gf(cdiv(cdiv(HW, FLAT_WAVE_PX), NT / 64), B);
+        const bool fvec = HW % 4 == 0 && HW >= 4 && aligned16(g_out) && aligned16(g_pat0) && aligned4(layer_u8);
+        if (fvec) FC3D_LAUNCH("code_pattern_bwd", (code_pattern_flat_bwd_kernel<true, true>), gf, dim3(NT), 0, s, g_out, (const float*)nullptr, layer_u8, max_in, (unsigned)HW, (float*)nullptr, g_pat0, (const int*)argmax_i32, dot_partial, n_partial);
+        else FC3D_LAUNCH("code_pattern_bwd", (code_pattern_flat_bwd_kernel<false, true>), gf, dim3(NT), 0, s, g_out, (const float*)nullptr, layer_u8, max_in, (unsigned)HW, (float*)nullptr, g_pat0, (const int*)argmax_i32, dot_partial, n_partial);
+        return FC3D_OK;
+    }
     constexpr int R = kRollRowsBwdDot;
 #define FC3D_BWD_DOT_CASE(KV)                                                                                    \
     if (Kw == KV) {                                                                                              \

@@ -159,8 +159,9 @@ class CodePatternFn(torch.autograd.Function):
         if dot is not None:
             with _on_device(dev):
                 _check(_lib.fc3d_code_pattern_bwd_dot(_stream(), g.data_ptr(), dot.data_ptr(), dot.shape[1],
-                                                      layer.data_ptr(), mx.data_ptr(), am.data_ptr(), psf.data_ptr(),
-                                                      B, H, W, L, Kh, Kw, int(conv), gp.data_ptr()),
+                                                      layer.data_ptr(), mx.data_ptr(), am.data_ptr(),
+                                                      psf.data_ptr() if conv else None, B, H, W, L, Kh, Kw, int(conv),
+                                                      gp.data_ptr()),
                        "fc3d_code_pattern_bwd_dot")
             return gp, None, None, None, None
         ws = torch.empty(max(1, _lib.fc3d_code_pattern_bwd_workspace(B, H, W) // 4), dtype=torch.float32, device=dev)

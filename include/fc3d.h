@@ -118,8 +118,8 @@ int fc3d_code_pattern_bwd(void *stream, const float *g_out, const float *out, co
  * known already, as n_partial partial sums per image (dot_partial[b * n_partial + i], added here in a
  * fixed order; fc3d_bilinear_bwd_img_dot produces them while it writes g_out): `out` is not read,
  * no workspace is needed, and the share of the per-image maximum goes in at its source pixel, so the
- * whole backward is one launch.  Square odd PSFs from 3x3 to 33x33 with conv_flag set
- * (fc3d_code_pattern_bwd_dot_supported); FC3D_EINVAL otherwise.                               */
+ * whole backward is one launch.  Square odd PSFs from 3x3 to 33x33, or conv_flag == 0 (psf may be
+ * NULL then) (fc3d_code_pattern_bwd_dot_supported); FC3D_EINVAL otherwise.                    */
 int fc3d_code_pattern_bwd_dot_supported(int Kh, int Kw, int conv_flag);
 int fc3d_code_pattern_bwd_dot(void *stream, const float *g_out, const float *dot_partial, int n_partial,
                               const uint8_t *layer_u8, const float *max_in, const int32_t *argmax_i32,

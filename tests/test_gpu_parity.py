@@ -521,7 +521,7 @@ def test_warp_pose_in_kernel_matches_separate_transforms(mods, golden, monkeypat
     assert int(mask.count_nonzero()) > 0            # mask_rezero = 0: the mask stays available
 
 
-@pytest.mark.parametrize("K", [3, 5, 7, 9, 23])
+@pytest.mark.parametrize("K", [3, 5, 7, 9, 23, 0])
 def test_backward_hands_sum_from_sampler_to_code_pattern(mods, K):
     """codePattern -> warp_p2c backward: the sampler's image-gradient kernel hands sum(g * Ip_coded) to
     codePattern's backward (one launch, `out` not read, the maximum's share applied at its source pixel).
@@ -530,7 +530,8 @@ def test_backward_hands_sum_from_sampler_to_code_pattern(mods, K):
     G, O, ops, synth = mods["G"], mods["O"], mods["ops"], mods["synth"]
     B, H, W, L = 3, 150, 276, 21                       # ragged: tiles and strips that hang over the image
     sc = synth.make_scene(B, H, W, seed=31)
-    O.PSFs_np = synth.make_psfs(L, K, "disc")
+    conv = K > 0                                       # K = 0: is_conv_psf=False, the streaming kernels
+    O.PSFs_np = synth.make_psfs(L, K if conv else 5, "disc")
     Kmat = dev(np.diag([1666.67, 1666.67, 1, 1]).astype(np.float32))
     Kmat[0, 2], Kmat[1, 2] = W / 2, H / 2
     rays = G.pixel_to_ray_array(W, H)
@@ -556,7 +557,7 @@ def test_backward_hands_sum_from_sampler_to_code_pattern(mods, K):
     try:
         for mode in ("handed", "touched", "no_offer"):
             pat = dev(p0).requires_grad_(True)
-            Ip = O.codePattern(pat, dev(sc["z_p"]), n_layers=L)
+            Ip = O.codePattern(pat, dev(sc["z_p"]), is_conv_psf=conv, n_layers=L)
             if mode == "touched":
                 Ip.register_hook(lambda g: g.mul_(1.0))          # in place: same tensor, new version
             if mode == "no_offer":
