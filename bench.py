@@ -217,9 +217,11 @@ def main():
     if args.launch == "graph":
         from fc3d.graphs import GraphedImageFormation
         # the K timed steps go out as K / unroll launches of a graph that holds `unroll` consecutive
-        # steps (the largest divisor of K up to 10): same kernels, order and buffers as K single-step
+        # steps (the largest common divisor of K and W up to 10): same kernels, order and buffers as K single-step
         # replays, without the pause between two graph launches after every step
-        unroll = max(u for u in range(1, 11) if args.steps % u == 0)
+        # ... that also divides W, so that the warm-up steps run the very graph (and touch the very buffers)
+        # that the timed steps use
+        unroll = max(u for u in range(1, 11) if args.steps % u == 0 and (args.warmup <= 0 or args.warmup % u == 0))
         try:
             gf = GraphedImageFormation(tens["pat"], tens["z_p"], tens["coord_p"], tens["coord_c"], tens["pose"],
                                        tens["g"], tens["L"], unroll=unroll, overlap=args.overlap)
