@@ -558,15 +558,16 @@ def warp_p2c_begin(coord_p: torch.Tensor, pose: torch.Tensor, K: torch.Tensor) -
         if _img_grad_ordered():        # the atomic form of the image gradient reads the mask again: no pooling then
             h.pool_key, h.mask = _pooled_zero_mask(B, H, W, dev, s, torch.cuda.is_current_stream_capturing())
         h.pooled = h.mask is not None
+        if h.pooled:
+            # checked out until the second half has cleared it again: a first half that is never finished
+            # must not leave a marked mask behind for the next call
+            _zero_masks.pop(h.pool_key, None)
         if not h.pooled:
             h.mask = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
-        status = _lib.fc3d_warp_project_splat(s, coord_p.data_ptr(), sp[0], sp[1], sp[2], sp[3], po.data_ptr(),
-                                              K.data_ptr(), k_sb, B, H, W, h.grid_p2c.data_ptr(), h.mask.data_ptr(),
-                                              int(h.pooled), h.transforms[0].data_ptr(), h.transforms[1].data_ptr(),
-                                              None)
-        if status != 0 and h.pooled:
-            _zero_masks.pop(h.pool_key, None)
-        _check(status, "fc3d_warp_project_splat")
+        _check(_lib.fc3d_warp_project_splat(s, coord_p.data_ptr(), sp[0], sp[1], sp[2], sp[3], po.data_ptr(),
+                                            K.data_ptr(), k_sb, B, H, W, h.grid_p2c.data_ptr(), h.mask.data_ptr(),
+                                            int(h.pooled), h.transforms[0].data_ptr(), h.transforms[1].data_ptr(),
+                                            None), "fc3d_warp_project_splat")
     return h
 
 
@@ -603,9 +604,9 @@ class WarpSampleFn(torch.autograd.Function):
                                            begun.transforms[1].data_ptr(), B, H, W, mask.data_ptr(), int(begun.pooled),
                                            Ic.data_ptr(), gc2p.data_ptr(),
                                            index.data_ptr() if index is not None else None)
-            if status != 0 and begun.pooled:
-                _zero_masks.pop(begun.pool_key, None)
             _check(status, "fc3d_warp_sample")
+            if begun.pooled:
+                _zero_masks[begun.pool_key] = mask        # cleared again by the kernel just launched: back to the pool
         ctx.save_for_backward(gc2p, None if begun.pooled else mask, index, ip if index is not None else None)
         ctx.mark_non_differentiable(gc2p)
         ctx.set_materialize_grads(False)
