@@ -155,8 +155,13 @@ class GraphedCapture:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"), torch.no_grad():
+        # on the warm-up's stream, so that the self-clearing visibility mask made there is the one captured
+        with torch.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"), torch.no_grad():
             self.outputs = self._call()
+        with torch.cuda.stream(side):
+            self.graph.replay()                    # the first launch of an instantiated graph does one-time work
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
 
     def replay(self):
         self.graph.replay()
