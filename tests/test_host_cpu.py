@@ -54,6 +54,34 @@ def test_cabi_exports_every_declared_symbol():
                                  one, 0, None) == -2
     assert lib.fc3d_capture_warp_fwd(None, one, one, one, one, one, one, one, 1, *big, one, one, one, 0, None, None) == -2
     assert lib.fc3d_bilinear_bwd_img(None, one, one + 8, None, 1, 8, 8, 1, *big, None, 0, one) == -2
+    # the entry points added for the six-launch step and the five-launch capture: null arguments, sizes that
+    # do not fit, PSF shapes without a kernel -- all refused before any device work
+    from fc3d._native import LayerGrid
+    lg = LayerGrid(1.0, 1.0, 1.0, 0.0, 21)
+    nk = __import__("ctypes").c_int(0)
+    assert lib.fc3d_warp_p2c_pose_fwd(None, one, one, 0, 0, 0, 0, one, 0, 0, 0, 0, None, one, 0, 1, 8, 8, one, one + 8,
+                                      one + 16, one, 0, 0, None, one, one, None) == -1        # no pose
+    assert lib.fc3d_warp_p2c_pose_fwd(None, one, one, 0, 0, 0, 0, one, 0, 0, 0, 0, one, one, 0, 1, *big, one, one + 8,
+                                      one + 16, one, 0, 0, None, one, one, None) == -2
+    assert lib.fc3d_warp_project_splat(None, one, 0, 0, 0, 0, one, None, 0, 1, 8, 8, one + 8, one, 0, one, one, None) == -1
+    assert lib.fc3d_warp_project_splat(None, one, 0, 0, 0, 0, one, one, 0, 1, *big, one + 8, one, 0, one, one, None) == -2
+    assert lib.fc3d_warp_sample(None, one, one, 0, 0, 0, 0, None, 1, 8, 8, one, 0, one, one + 8, None) == -1
+    assert lib.fc3d_warp_sample(None, one, one, 0, 0, 0, 0, one, 1, *big, one, 0, one, one + 8, None) == -2
+    assert lib.fc3d_bilinear_bwd_img_dot_count(512, 512) == 8 * 43 and lib.fc3d_bilinear_bwd_img_dot_count(0, 5) == 0
+    assert lib.fc3d_bilinear_bwd_img_dot(None, one, one + 8, 1, 8, 8, 8, 8, one + 8, None, one, one) == -1      # no image
+    assert lib.fc3d_bilinear_bwd_img_dot(None, one, one + 8, 1, 8, 8, *big, one + 8, one, one, one) == -2
+    assert lib.fc3d_code_pattern_bwd_dot_supported(5, 5, 1) == 1 and lib.fc3d_code_pattern_bwd_dot_supported(23, 23, 1) == 1
+    assert lib.fc3d_code_pattern_bwd_dot_supported(8, 8, 1) == 0 and lib.fc3d_code_pattern_bwd_dot_supported(5, 3, 1) == 0
+    assert lib.fc3d_code_pattern_bwd_dot_supported(1, 1, 0) == 1
+    assert lib.fc3d_code_pattern_bwd_dot(None, one, one, 4, one, one, one, one, 1, 8, 8, 21, 8, 8, 1, one) == -1  # even PSF
+    assert lib.fc3d_code_pattern_bwd_dot(None, one, None, 4, one, one, one, one, 1, 8, 8, 21, 5, 5, 1, one) == -1
+    assert lib.fc3d_code_pattern_shaded_conv_fwd(None, one, 0, 8, 1, one, one, 1, 8, 8, 9, 9, lg, one, None, one,
+                                                 __import__("ctypes").byref(nk)) == -1                           # 9x9: no rolling-row kernel
+    assert lib.fc3d_capture_fwd_workspace(32, 512, 512) == (32 * 32 + 32 * 512) * 4 and lib.fc3d_capture_fwd_workspace(0, 1, 1) == 0
+    assert lib.fc3d_capture_fwd(None, one, one, one, one, one, None, one, 0, one, one, one, 1, 8, 8, one, one, one, one,
+                                one, 0, 0, one, None, None) == -1
+    assert lib.fc3d_capture_fwd(None, one, one, one, one, one, one, one, 0, one, one, one, 1, *big, one, one, one, one,
+                                one, 0, 0, one, None, None) == -2
     # more partial sums than the library's static array holds: refused before any device work
     assert lib.fc3d_reproj_loss_fwd_static(None, one, one, one, one, one, one, one, one, 300, 512, 512, 512, 512,
                                            one, one) == -4
