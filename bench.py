@@ -76,6 +76,11 @@ def parse():
                          "join cost more than the overlap of the two kernels gives)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--n1-value", type=float, default=None,
+                    help="captures/s of a previous --gpus 1 run: the line then carries scaling_efficiency_vs_n1")
+    ap.add_argument("--launch-selftest", action="store_true",
+                    help="exercise the launch / rendezvous / max-over-ranks / reporting path with gloo ranks and a host "
+                         "stand-in for the step: touches no GPU (for machines without one and for CPU tests)")
     return ap.parse_args()
 
 
@@ -185,15 +190,78 @@ def copy_bandwidth(device, mib=512, iters=10):
     return 2.0 * n * 4 * iters / (a.elapsed_time(b) * 1e-3)
 
 
+def rank_rates(value_rank, world, dist, device):
+    """Every rank's own rate (its captures / its own elapsed time), gathered on all ranks."""
+    if dist is None:
+        return [value_rank]
+    t = torch.zeros(world, dtype=torch.float64, device=device)
+    t[dist.get_rank()] = value_rank
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(v) for v in t.tolist()]
+
+
+def scaling_fields(args, value, world, dist_world, per_rank):
+    out = {"world_size": dist_world,
+           "per_rank_captures_per_s": {"min": min(per_rank), "max": max(per_rank)}}
+    if args.n1_value:
+        out["scaling_efficiency_vs_n1"] = value / (world * args.n1_value)
+    return out
+
+
+def selftest(args, world, rank):
+    """The N-rank plumbing of this benchmark without a GPU: rendezvous (gloo), barrier, K timed stand-in
+    steps, MAX over ranks, one JSON line from rank 0."""
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo")
+    B = args.batch or 2
+    x = np.random.RandomState(100 * rank).rand(B, 64, 64).astype(np.float32)
+
+    def step():
+        return float(np.sqrt(x * x + 1.0).sum())
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    own = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    per_rank = rank_rates(B * args.steps / own, world, dist if world > 1 else None, "cpu")
+    if rank == 0:
+        value = world * B * args.steps / elapsed
+        out = {"metric": "launch self-test (host stand-in step, no GPU)", "selftest": True, "value": value,
+               "unit": "stand-in steps*batch/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": 1e3 * elapsed / args.steps, "scaling": "weak",
+               "config": {"global_batch": world * B, "parallelism": f"batch-sharded x{world}, no collective"}}
+        out.update(scaling_fields(args, value, world, dist.get_world_size() if world > 1 else 1, per_rank))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    from fc3d import launch as launcher
+    if args.gpus > 1 and not launcher.launched_by_torchrun():
+        # invoked plainly: start the N ranks as child processes (one per GPU) before this process has made
+        # any GPU call, relay their output and leave with their status
+        sys.exit(launcher.spawn_ranks(__file__, sys.argv[1:], args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
         sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.launch_selftest:
+        return selftest(args, world, rank)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local)
@@ -254,12 +322,37 @@ def main():
     barrier()
     t0 = time.perf_counter()
     run_steps(args.steps)
+    torch.cuda.synchronize()
+    own = time.perf_counter() - t0          # this rank's own K steps (per-rank rates below)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    per_rank = rank_rates(cfg["B"] * args.steps / own, world, dist, device)
+
+    # the same K steps issued the two other ways, after the timed region (reported beside the headline): one
+    # graph launch per step -- what a caller that runs one step per iteration sees -- and launch by launch
+    def timed(fn, k):
+        fn(min(k, 5))
+        torch.cuda.synchronize()
+        a = time.perf_counter()
+        fn(k)
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - a) / k
+
+    def eager_steps(k):
+        for _ in range(k):
+            step()
+    ms_graph_x1 = ms_eager = None
+    if rank == 0:
+        if launch.startswith("hip_graph"):
+            def single_replays(k):
+                for _ in range(k):
+                    gf.replay()
+            ms_graph_x1 = timed(single_replays, args.steps)
+        ms_eager = timed(eager_steps, args.steps)
 
     # the replayed step must give what eager launches give (guards the timed number against a
     # capture that silently computes something else)
@@ -295,6 +388,8 @@ def main():
             "value": value, "unit": "captures/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "ms_per_step_graph_x1": ms_graph_x1, "ms_per_step_eager": ms_eager,
+            **scaling_fields(args, value, world, dist.get_world_size() if dist is not None else 1, per_rank),
             "config": {"workload": f"{args.workload}: {B}x{H}x{W} per GPU, L={cfg['L']} depth layers, "
                                    f"{cfg['K']}x{cfg['K']} '{args.psf_kind}' PSFs, pose theta<={cfg['theta_deg']}deg; "
                                    "codePattern -> warp_p2c fwd + bwd to pattern[...,0]",

@@ -38,7 +38,13 @@ def main():
                          "batch semantics); rank_mean: per-rank losses, averaged gradients")
     ap.add_argument("--buckets", type=int, default=3, help="ranges the 69 MB gradient buffer is all-reduced in")
     ap.add_argument("--no-overlap", action="store_true", help="start the all-reduce after backward instead of from hooks")
+    ap.add_argument("--n1-value", type=float, default=None,
+                    help="steps/s of a previous --gpus 1 run: the line then carries scaling_efficiency_vs_n1")
     args = ap.parse_args()
+    from fc3d import launch as launcher
+    if args.gpus > 1 and not launcher.launched_by_torchrun():
+        # invoked plainly: the N ranks are started as child processes before this process makes any GPU call
+        sys.exit(launcher.spawn_ranks(__file__, sys.argv[1:], args.gpus))
     from fc3d import capture, dist as fdist, synth
     import optics_pytorch as O
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -76,10 +82,14 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step(z_p, z_c, pose)
+    torch.cuda.synchronize()
+    own = time.perf_counter() - t0
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     el = fdist.max_over_ranks(time.perf_counter() - t0, dev)
+    slowest_own = fdist.max_over_ranks(own, dev)
+    fastest_own = -fdist.max_over_ranks(-own, dev)
     # where the step goes: the capture simulation alone, timed the same way
     with torch.no_grad():
         capture.forward_model(z_p, z_c, pose, 21, True, None, intrinsics=(W / 2, H / 2))
@@ -93,6 +103,9 @@ def main():
         print(json.dumps({"metric": "training steps/sec (capture simulation + 2 U-Nets + reproj loss + Adam), data parallel",
                           "value": args.steps / el, "unit": "steps/s", "samples_per_s": world * args.batch * args.steps / el,
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
+                          "world_size": torch.distributed.get_world_size() if world > 1 else 1,
+                          "per_rank_steps_per_s": {"min": args.steps / slowest_own, "max": args.steps / fastest_own},
+                          **({"scaling_efficiency_vs_n1": (args.steps / el) / args.n1_value} if args.n1_value else {}),
                           "scaling": "weak", "dtype": "f32", "data": "synthetic",
                           "config": {"workload": f"{args.batch}x{H}x{W} per GPU, global batch {world * args.batch}",
                                      "grad_allreduce_bytes": step.bucket.nbytes, "grad_ranges": len(step.bucket.ranges),

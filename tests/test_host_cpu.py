@@ -322,6 +322,35 @@ def test_data_parallel_helpers_gloo_two_ranks(tmp_path):
     assert r.stdout.count("ok") == 2
 
 
+def test_bench_starts_its_own_ranks_when_invoked_plainly():
+    """`python bench.py --gpus 2` without torch.distributed.run's environment starts two ranks as child
+    processes and relays rank 0's line.  --launch-selftest runs the rendezvous / barrier / max-over-ranks /
+    reporting path with gloo and a host stand-in for the step: no GPU call is made anywhere."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-selftest", "--steps", "8",
+                        "--warmup", "2", "--n1-value", "1000"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                       # exactly one line, from rank 0
+    d = json.loads(lines[0])
+    assert d["selftest"] is True and d["n_gpus"] == 2 and d["world_size"] == 2 and d["steps"] == 8
+    assert d["config"]["global_batch"] == 4 and d["scaling"] == "weak"
+    pr = d["per_rank_captures_per_s"]
+    assert 0 < pr["min"] <= pr["max"]
+    assert d["value"] <= 2 * pr["max"] * 1.0001            # whole-job rate: never above the sum of the ranks' own rates
+    assert abs(d["scaling_efficiency_vs_n1"] - d["value"] / 2000.0) < 1e-9
+    # a mismatch between --gpus and the environment of an outer launcher is refused, not silently run
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-selftest"],
+                         env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE=1" in bad.stderr
+    from fc3d import launch
+    cmd = launch.rank_command("x.py", ["--gpus", "4"], 4, port=29999)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-2:] == ["--gpus", "4"]
+
+
 def test_capture_data_shards(tmp_path):
     """The .npz reader: stored values passed through as float32 like the reference's loader
     (data_provider_pytorch.py:32-36), optional decoding of raw uint16 codes (value/50000 + 0.3), split
