@@ -230,11 +230,23 @@ def reProj_IpGT(zp_cView, pose_p2c, xy, Ic, zcGT, maskC, IpGT, fused=True, intri
     return loss_Ic_L1 + loss_zc_rms, loss_zc_rms, loss_Ic_rms, loss_Ic_L1
 
 
+def _rms_sums(GT, hat, mask):
+    """The two sums of cost_rms_mask (utils_pytorch.py:161-163): masked squared error and mask count."""
+    return torch.sum(torch.square(mask * (GT - hat))), torch.sum(mask)
+
+
 def cal_cost(xyz, xyz_hat, mask, reduce=_same):
-    """Reconstruction loss; train_pytorch.py:214-230."""
-    l_xy = cost_rms_mask(xyz[..., :2], xyz_hat[..., :2], mask, reduce=reduce)
-    l_z = cost_rms_mask(xyz[..., 2:3], xyz_hat[..., 2:3], mask, reduce=reduce)
-    l_g = cost_grad_mask(xyz[..., 2:3], xyz_hat[..., 2:3], erode(mask, 5), reduce=reduce)
+    """Reconstruction loss; train_pytorch.py:214-230.  reduce (fc3d.dist.sum_over_ranks for the loss over the
+    global batch of a data-parallel step) is applied ONCE, to the vector of the eight masked sums and mask counts
+    the four RMS terms are made of, not term by term: one collective instead of eight."""
+    me = erode(erode(mask, 5), 9)                       # cost_grad_mask erodes the already eroded mask again
+    GTy, GTx = image_gradients(xyz[..., 2:3])
+    hy, hx = image_gradients(xyz_hat[..., 2:3])
+    terms = (_rms_sums(xyz[..., :2], xyz_hat[..., :2], mask), _rms_sums(xyz[..., 2:3], xyz_hat[..., 2:3], mask),
+             _rms_sums(GTx, hx, me), _rms_sums(GTy, hy, me))
+    S = reduce(torch.stack([v for nd in terms for v in nd]))
+    rms = [torch.sqrt(S[2 * i] / S[2 * i + 1].clamp(min=1e-6) + 1e-6) for i in range(4)]
+    l_xy, l_z, l_g = rms[0], rms[1], rms[2] + rms[3]
     return l_xy + l_z + l_g, l_xy, l_z, l_g
 
 
@@ -266,6 +278,8 @@ class TrainStep:
         self.opt = torch.optim.Adam(self.params, lr=lr)
         self.n_layers, self.is_conv_psf, self.crop, self.w = n_layers, is_conv_psf, crop, weight_reproj
         self.loss_mode = loss
+        self.keep_capture = False          # True: the simulated capture of the last step stays in self.last_capture
+        self.last_capture = None
         self._reduce = fdist.sum_over_ranks if loss == "global" else None
         self._world = fdist.dist.get_world_size() if (fdist.dist.is_available() and fdist.dist.is_initialized()) else 1
 
@@ -275,6 +289,8 @@ class TrainStep:
         with torch.no_grad():
             (Ic_s, Ic_m, xyz, xy, zc, zp, pose, _zp_full, Ic, Ip_coded, _) = forward_model(
                 z_p, z_c, pose_p2c, self.n_layers, self.is_conv_psf, self.crop, noise, intrinsics=self.intrinsics)
+        if self.keep_capture:
+            self.last_capture = dict(Ic_scaled=Ic_s, Ic_mask=Ic_m, xyz_cView=xyz, Ic=Ic, Ip_coded=Ip_coded)
         inp = local_norm(Ic_s, 17, 0.01)
         xyz_hat = torch.cat([self.model_xy(inp), self.model_z(inp)], dim=-1)
         red = self._reduce

@@ -130,11 +130,23 @@ class FlatGradBucket:
 
     def _make_hook(self, b):
         def hook(_param):
+            if self._pending[b] <= 0:
+                # a second backward without zero(): this range's transfer is already in flight (or done) and
+                # would be reduced again on top of the summed values
+                raise RuntimeError("FlatGradBucket(overlap=True): a gradient arrived for a range whose all-reduce "
+                                   "has been started already; call zero() before every backward (gradient "
+                                   "accumulation over several backward passes needs overlap=False)")
             self._pending[b] -= 1
             if self._pending[b] == 0 and self._active():
                 lo, hi, _ = self.ranges[b]
                 self._handles.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
         return hook
+
+    def close(self):
+        """Removes the autograd hooks (the gradients stay views of the flat buffer)."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
 
     @property
     def nbytes(self) -> int:

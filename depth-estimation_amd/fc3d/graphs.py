@@ -141,11 +141,16 @@ class GraphedCapture:
     static too and are overwritten by the next replay."""
 
     def __init__(self, z_p, z_c, pose, noise, n_layers=21, is_conv_psf=True, crop=None, pattern=None,
-                 warmup: int = 3):
+                 warmup: int = 3, intrinsics=None):
+        """intrinsics: as for fc3d.capture.forward_model -- None (the reference's matrix, 800x1200 images only),
+        a (cx, cy) principal point, or a [4,4] / [B,4,4] tensor (made before the capture: an upload inside the
+        captured region cannot be replayed)."""
         from . import capture
         self.z_p, self.z_c, self.pose, self.noise = z_p, z_c, pose, noise
+        if intrinsics is not None and z_p.shape[0] > 0:
+            intrinsics = capture.resolve_intrinsics(intrinsics, z_p.shape[0], z_p.shape[1], z_p.shape[2], z_p.device)
         self._call = lambda: capture.forward_model(z_p, z_c, pose, n_layers, is_conv_psf, crop, noise, pattern,
-                                                   fused=True)
+                                                   fused=True, intrinsics=intrinsics)
         dev = z_p.device
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))

@@ -7,6 +7,7 @@ is deliberately no CPU path.
 from __future__ import annotations
 
 import ctypes
+import threading
 
 import numpy as np
 import torch
@@ -439,25 +440,47 @@ class WarpP2CFn(torch.autograd.Function):
 
 # Visibility-mask buffers that hold zeros between calls: fc3d_warp_p2c_pose_fwd's sampling kernel
 # stores zeros back into the mask it has just consumed, so a buffer is cleared once, when it is
-# made, and never again.  One buffer per (device, stream, shape): calls on one stream are ordered.
-# A buffer that a stream capture has used stays for good (the graph replays write to its address);
-# a capture only uses a buffer that exists already, i.e. one made by eager calls on the same stream.
+# made, and never again.  One buffer per (device, stream, shape, host thread): calls of one thread
+# on one stream are ordered, and two host threads never share a buffer.  Where the two halves of a
+# warp run on different streams (warp_p2c_begin / WarpSampleFn), the second half leaves an event
+# behind and the next checkout of the buffer waits for it, so the next splat cannot overtake the
+# kernel that is still reading and clearing the mask.  A buffer that a stream capture has used stays
+# for good (the graph replays write to its address); a capture only uses a buffer that exists
+# already, i.e. one made by eager calls on the same stream, and orders its streams itself.
+# set_mask_pooling(False) opts out: every call then gets a fresh mask that the kernels clear.
 _zero_masks: dict = {}
 _zero_masks_pinned: set = set()
+_zero_mask_events: dict = {}
+_MASK_POOLING = True
+
+
+def set_mask_pooling(on: bool) -> bool:
+    """Whether warp_p2c / the capture simulator keep self-clearing visibility-mask buffers between calls
+    (default) or allocate and clear one per call.  Returns the previous setting."""
+    global _MASK_POOLING
+    old, _MASK_POOLING = _MASK_POOLING, bool(on)
+    return old
 
 
 def _pooled_zero_mask(B, H, W, dev, stream, capturing):
-    key = (dev.index, stream, B, H, W)
+    if not _MASK_POOLING:
+        return None, None
+    key = (dev.index, stream, B, H, W, threading.get_ident())
     m = _zero_masks.get(key)
     if m is None:
         if capturing:
             return key, None
         for k in [k for k in _zero_masks if k not in _zero_masks_pinned][:max(0, len(_zero_masks) - 7)]:
             del _zero_masks[k]
+            _zero_mask_events.pop(k, None)
         m = torch.zeros((B, H, W), dtype=torch.uint8, device=dev)
         _zero_masks[key] = m
     if capturing:
         _zero_masks_pinned.add(key)
+    else:
+        ev = _zero_mask_events.pop(key, None)
+        if ev is not None:          # last cleared by a kernel on another stream: order this stream behind it
+            torch.cuda.current_stream(dev).wait_event(ev)
     return key, m
 
 
@@ -534,13 +557,15 @@ class WarpP2CPoseFn(torch.autograd.Function):
 
 class WarpBegun:
     """What the first launch of warp_p2c (projection of coord_p + visibility splat) leaves for the second."""
-    __slots__ = ("grid_p2c", "mask", "transforms", "pooled", "pool_key", "shape")
+    __slots__ = ("grid_p2c", "mask", "transforms", "pooled", "pool_key", "shape", "stream")
 
 
 def warp_p2c_begin(coord_p: torch.Tensor, pose: torch.Tensor, K: torch.Tensor) -> WarpBegun:
     """The half of warp_p2c that needs neither the image nor coord_c (geometry_pytorch.py:276-277): grid_p2c,
     the visibility mask, and K*pose / K*inverse(pose) formed on the side.  It may be issued on another stream,
-    beside the work that produces the image; the caller orders that stream before WarpSampleFn."""
+    beside the work that produces the image; the caller orders that stream before WarpSampleFn
+    (`main.wait_stream(side)`), nothing more: the ordering of the NEXT first half behind this warp's second half
+    (which reads and clears the pooled mask on the main stream) is kept by an event stored with the buffer."""
     dev = _need_gpu(coord_p, pose, K)
     coord_p, sp = _coord_args(coord_p.detach())
     B, _, H, W = coord_p.shape
@@ -558,6 +583,7 @@ def warp_p2c_begin(coord_p: torch.Tensor, pose: torch.Tensor, K: torch.Tensor) -
         if _img_grad_ordered():        # the atomic form of the image gradient reads the mask again: no pooling then
             h.pool_key, h.mask = _pooled_zero_mask(B, H, W, dev, s, torch.cuda.is_current_stream_capturing())
         h.pooled = h.mask is not None
+        h.stream = s
         if h.pooled:
             # checked out until the second half has cleared it again: a first half that is never finished
             # must not leave a marked mask behind for the next call
@@ -594,19 +620,29 @@ class WarpSampleFn(torch.autograd.Function):
             raise RuntimeError("the image-gradient mode changed between the two halves of warp_p2c")
         mask, begun.mask = begun.mask, None
         with _on_device(dev):
-            if not torch.cuda.is_current_stream_capturing():
-                # the first half may have run (and allocated) on another stream: tell the allocator who reads
+            s = _stream()
+            capturing = torch.cuda.is_current_stream_capturing()
+            cross = s != begun.stream
+            if cross and not capturing:
+                # the first half ran (and allocated) on another stream: tell the allocator who reads
                 here = torch.cuda.current_stream()
                 begun.transforms.record_stream(here)
+                begun.grid_p2c.record_stream(here)
                 if not begun.pooled:
                     mask.record_stream(here)
-            status = _lib.fc3d_warp_sample(_stream(), ip.data_ptr(), coord_c.data_ptr(), sc[0], sc[1], sc[2], sc[3],
+            status = _lib.fc3d_warp_sample(s, ip.data_ptr(), coord_c.data_ptr(), sc[0], sc[1], sc[2], sc[3],
                                            begun.transforms[1].data_ptr(), B, H, W, mask.data_ptr(), int(begun.pooled),
                                            Ic.data_ptr(), gc2p.data_ptr(),
                                            index.data_ptr() if index is not None else None)
             _check(status, "fc3d_warp_sample")
             if begun.pooled:
-                _zero_masks[begun.pool_key] = mask        # cleared again by the kernel just launched: back to the pool
+                # cleared again by the kernel just launched: back to the pool -- with an event if that kernel runs
+                # on another stream than the one the buffer belongs to, for the next checkout to wait on
+                if cross and not capturing:
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream())
+                    _zero_mask_events[begun.pool_key] = ev
+                _zero_masks[begun.pool_key] = mask
         ctx.save_for_backward(gc2p, None if begun.pooled else mask, index, ip if index is not None else None)
         ctx.mark_non_differentiable(gc2p)
         ctx.set_materialize_grads(False)

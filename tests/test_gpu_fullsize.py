@@ -138,6 +138,42 @@ def test_full_size_properties(env, monkeypatch, name):
     assert rel_err(gpat[b:b + 1].cpu().numpy(), pc.grad[..., 0:1].numpy()) < 5e-4
 
 
+@pytest.mark.parametrize("pattern_kind", ["dots", "uniform"])
+def test_c1_one_256_scene_against_the_oracle(env, monkeypatch, pattern_kind):
+    """The first benchmark configuration exactly -- one 256 x 256 scene, batch 1, 21 layers, 5x5 PSFs --
+    end to end against the CPU oracle (the reference's operators restated; it is handed the library's
+    inverse pose so that LAPACK's last bit does not enter): projected grids, visibility mask and layer
+    index bit for bit, coded pattern, capture and pattern gradient to 1e-4 of the scale and per element."""
+    G, O, ops, orc = env["G"], env["O"], env["ops"], env["orc"]
+    wl, cfg, t = load(env, "C1", monkeypatch, pattern_kind=pattern_kind)
+    assert (cfg["B"], cfg["H"], cfg["W"], cfg["L"], cfg["K"]) == (1, 256, 256, 21, 5)
+    H, W, L = cfg["H"], cfg["W"], cfg["L"]
+    Ip, Ic, gp2c, gc2p, gpat = run(env, t, L)
+    _, _, inv = ops.pose_transforms(t["pose"], None, want_a=True)
+    c = lambda a: a.detach().cpu()  # noqa: E731
+    pc = c(t["pat"]).expand(-1, -1, -1, L).clone().requires_grad_(True)
+    cp, cc = orc.z2pointcloud(c(t["z_p"])), orc.z2pointcloud(c(t["z_c"]))
+    Ip_r = orc.codePattern(pc, c(t["z_p"]), wl["psfs"], True)
+    Ic_r, gp_r, gc_r = orc.warp_p2c(Ip_r, cp, cc, c(t["pose"]), W / 2, H / 2, pose_c2p=c(inv))
+    Ic_r.backward(c(t["g"]))
+    assert np.array_equal(c(gp2c).numpy(), gp_r.numpy())
+    assert np.array_equal(c(gc2p).numpy(), gc_r.detach().numpy())
+    mask = G.gen_visible_mask(gp2c, "all")
+    assert np.array_equal(c(mask).numpy(), orc.gen_visible_mask(gp_r, "all").numpy())
+    _, layer, _, _ = ops.CodePatternFn.apply(t["pat"], t["z_p"], O._device_psfs(t["pat"].device), O._layer_grid(L), True)
+    got = layer.cpu().numpy().astype(np.int64)
+    got[got == 255] = -1
+    assert np.array_equal(got, orc.layer_index(c(t["z_p"]), L)[..., 0].numpy())
+    assert rel_err(c(Ip).numpy(), Ip_r.detach().numpy()) < TOL and rel_err_elem(c(Ip).numpy(), Ip_r.detach().numpy()) < TOL
+    assert rel_err(c(Ic).numpy(), Ic_r.detach().numpy()) < TOL and rel_err_elem(c(Ic).numpy(), Ic_r.detach().numpy()) < TOL
+    # the gradient: interior element by element; the one-pixel border ring also collects the exactly cancelling
+    # +w / -w taps of samples outside the image, whose fp32 rounding residue in the reference is not a target
+    ga, gr = c(gpat).numpy(), pc.grad[..., 0:1].numpy()
+    assert rel_err(ga, gr) < TOL
+    inner = (slice(None), slice(3, -3), slice(3, -3))     # the 5x5 blur spreads the ring two pixels inwards
+    assert rel_err_elem(ga[inner], gr[inner]) < TOL
+
+
 def test_c4_large_kernels(env, monkeypatch):
     """1024x1024, 41 layers, 23x23 and 33x33 PSFs (LDS holds only the layers a tile touches)."""
     G, O, synth, orc = env["G"], env["O"], env["synth"], env["orc"]

@@ -111,6 +111,10 @@ def test_code_pattern_golden(mods, golden):
         e2 = rel_err(pat.grad[..., 0:1].cpu().numpy(), g[f"{tag}_grad0"])
         worst = max(worst, e1, e2)
         assert e1 < TOL and e2 < TOL, (tag, psf, K, conv, pk, e1, e2)
+        # ... and element by element (where the reference value is not itself at rounding level)
+        e3 = rel_err_elem(out.detach().cpu().numpy(), g[f"{tag}_out"])
+        e4 = rel_err_elem(pat.grad[..., 0:1].cpu().numpy(), g[f"{tag}_grad0"])
+        assert e3 < TOL and e4 < TOL, (tag, psf, K, conv, pk, e3, e4)
         assert float(pat.grad[..., 1:].abs().max()) == 0.0
     print("code_pattern worst rel err", worst)
 
@@ -223,6 +227,7 @@ def test_project_bit_exact(mods, golden, monkeypatch):
     grid.backward(dev(g["g_grid"]))
     assert np.array_equal(grid.detach().cpu().numpy(), g["grid"])
     assert rel_err(c.grad.cpu().numpy(), g["grad_coord"]) < TOL
+    assert rel_err_elem(c.grad.cpu().numpy(), g["grad_coord"]) < TOL
     assert rel_err(pg.grad.cpu().numpy(), g["grad_pose"]) < TOL        # K^T (sum over pixels of g_u x coord)
     for b in range(pg.shape[0]):                                       # ... and per sample, entry by entry
         assert np.allclose(pg.grad[b].cpu().numpy(), g["grad_pose"][b], rtol=1e-3, atol=1e-4 * np.abs(g["grad_pose"][b]).max())
@@ -243,6 +248,7 @@ def test_project_bit_exact(mods, golden, monkeypatch):
     gr.backward(dev(g["g_grid_r"]))
     assert np.array_equal(gr.detach().cpu().numpy(), g["grid_r"])
     assert rel_err(cr.grad.cpu().numpy(), g["grad_coord_r"]) < TOL
+    assert rel_err_elem(cr.grad.cpu().numpy(), g["grad_coord_r"]) < TOL
     assert rel_err(trg.grad.cpu().numpy(), g["grad_tr"]) < TOL
     # only the transform asks for a gradient; a strided view of the points
     trg2 = dev(g["tr"]).requires_grad_(True)
@@ -318,6 +324,9 @@ def test_bilinear_golden(mods, golden, mode):
         e_img = rel_err(img.grad.cpu().numpy() * keep, g[f"{tag}_grad_img"] * keep)
         e_co = rel_err(co.grad.cpu().numpy(), g[f"{tag}_grad_coords"])
         assert e_img < TOL and e_co < TOL, (tag, e_img, e_co)
+        ee_img = rel_err_elem(img.grad.cpu().numpy() * keep, g[f"{tag}_grad_img"] * keep)
+        ee_co = rel_err_elem(co.grad.cpu().numpy(), g[f"{tag}_grad_coords"])
+        assert ee_img < TOL and ee_co < TOL, (tag, ee_img, ee_co)
     img = torch.arange(16.0, device="cuda").reshape(1, 4, 4, 1) + 1
     assert float(G.bilinear_sampler(img, torch.tensor([[[[3.0, 3.0]]]], device="cuda"))) == 0.0
 
@@ -653,6 +662,7 @@ def test_reproj_chain(mods, golden, monkeypatch):
     assert rel_err(grid.detach().cpu().numpy(), g["grid"]) < 1e-5
     assert rel_err(Ic.detach().cpu().numpy(), g["Ic"]) < TOL
     assert rel_err(zp.grad.cpu().numpy(), g["grad_zp"]) < TOL
+    assert rel_err_elem(zp.grad.cpu().numpy(), g["grad_zp"]) < TOL
 
 
 def test_reproject_fused(mods, golden, monkeypatch):
@@ -681,6 +691,7 @@ def test_reproject_fused(mods, golden, monkeypatch):
     assert rel_err(Ic2.detach().cpu().numpy(), Ic1.detach().cpu().numpy()) < TOL
     ((Ic2 * dev(g["g_ic"])).sum() + (zc2 * dev(g["g_zc"])).sum()).backward()
     assert rel_err(zp2.grad.cpu().numpy(), g["grad_zp"]) < TOL
+    assert rel_err_elem(zp2.grad.cpu().numpy(), g["grad_zp"]) < TOL
     for use in ("zc", "Ic"):
         a = dev(g["zp"]).requires_grad_(True)
         b = dev(g["zp"]).requires_grad_(True)

@@ -322,6 +322,31 @@ def test_data_parallel_helpers_gloo_two_ranks(tmp_path):
     assert r.stdout.count("ok") == 2
 
 
+def test_bucket_refuses_a_second_backward_without_zero():
+    """With overlap=True a range's all-reduce starts from the hook that completes it; a second backward
+    without zero() would add onto values that are already being summed over ranks.  The hook raises instead."""
+    from fc3d import dist as fdist
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Tanh(), torch.nn.Linear(3, 1))
+    x = torch.rand(5, 4)
+    bucket = fdist.FlatGradBucket(net.parameters(), n_buckets=2, overlap=True)
+    bucket.zero()
+    net(x).sum().backward()
+    g1 = bucket.flat.clone()
+    with pytest.raises(RuntimeError, match="zero\\(\\) before every backward"):
+        net(x).sum().backward()
+    bucket.zero()
+    net(x).sum().backward()
+    assert torch.equal(bucket.flat, g1)
+    bucket.close()
+    # without overlap there are no hooks: accumulating over two backward passes is allowed
+    acc = fdist.FlatGradBucket(net.parameters(), n_buckets=2, overlap=False)
+    acc.zero()
+    net(x).sum().backward()
+    net(x).sum().backward()
+    assert torch.allclose(acc.flat, 2 * g1)
+
+
 def test_bench_starts_its_own_ranks_when_invoked_plainly():
     """`python bench.py --gpus 2` without torch.distributed.run's environment starts two ranks as child
     processes and relays rank 0's line.  --launch-selftest runs the rendezvous / barrier / max-over-ranks /
