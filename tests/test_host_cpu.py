@@ -298,6 +298,7 @@ def masked_rms(gt, hat, m, reduce):
     return torch.sqrt(reduce(torch.sum(torch.square(m * (gt - hat)))) / reduce(torch.sum(m)).clamp(min=1e-6) + 1e-6)
 single.zero_grad()
 Ls = masked_rms(Y, single(X), M, lambda v: v); Ls.backward()
+bucket.close()                         # the hooks of the three-range bucket go; the next one registers its own
 bucket = fdist.FlatGradBucket(net.parameters(), n_buckets=2, overlap=True, average=False)
 bucket.zero()
 Lg = masked_rms(Y[sl], net(X[sl]), M[sl], fdist.sum_over_ranks); Lg.backward()
