@@ -104,13 +104,107 @@ __device__ __forceinline__ const FC3D_GLOBAL T* uniform_global(const T* p) {
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
     return reinterpret_cast<const FC3D_GLOBAL T*>(((uint64_t)hi << 32) | lo);
 }
+template <bool NT = false>
 __device__ __forceinline__ float ld_global(const FC3D_GLOBAL float* base, unsigned elem) {
-    return *reinterpret_cast<const FC3D_GLOBAL float*>(reinterpret_cast<const FC3D_GLOBAL char*>(base) + elem * 4u);
+    const FC3D_GLOBAL float* p = reinterpret_cast<const FC3D_GLOBAL float*>(reinterpret_cast<const FC3D_GLOBAL char*>(base) + elem * 4u);
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
 }
+template <bool NT = false>
 __device__ __forceinline__ float2 ld_global(const FC3D_GLOBAL float2* base, unsigned elem) {
     typedef float f2v __attribute__((ext_vector_type(2)));     // a plain vector: float2's copy constructor takes generic references only
-    const f2v v = *reinterpret_cast<const FC3D_GLOBAL f2v*>(reinterpret_cast<const FC3D_GLOBAL char*>(base) + elem * 8u);
+    const FC3D_GLOBAL f2v* p = reinterpret_cast<const FC3D_GLOBAL f2v*>(reinterpret_cast<const FC3D_GLOBAL char*>(base) + elem * 8u);
+    f2v v;
+    if constexpr (NT) v = __builtin_nontemporal_load(p);
+    else v = *p;
     return make_float2(v.x, v.y);
+}
+
+// Cache policy of streaming accesses.  A step moves about a gigabyte through a 32 MB L2 and a 256 MB
+// memory-side cache: what is read once (scene points, upstream gradients) or written and not read
+// again by the step (grids, the capture, the pattern gradient) is marked non-temporal, so that it does
+// not push out what a later kernel of the step reads again (the coded pattern, the layer indices, the
+// sampling grid).  FC3D_NT is a bit mask of tuning switches, one per stream (see FC3D_NT_* below).
+#ifndef FC3D_NT
+#define FC3D_NT 0x251f
+#endif
+#define FC3D_NT_BIT(b) ((((FC3D_NT) >> (b)) & 1) != 0)
+constexpr bool kNtProjLoad = FC3D_NT_BIT(0);      // projection: scene points of the projector view
+constexpr bool kNtProjStore = FC3D_NT_BIT(1);     // projection: grid_p2c
+constexpr bool kNtSampLoad = FC3D_NT_BIT(2);      // sampling: scene points of the camera view
+constexpr bool kNtSampGrid = FC3D_NT_BIT(3);      // sampling: grid_c2p (read again by the image-gradient pass)
+constexpr bool kNtSampOut = FC3D_NT_BIT(4);       // sampling: the masked capture
+constexpr bool kNtGatherLoad = FC3D_NT_BIT(5);    // image gradient: upstream gradient and grid_c2p (their last use)
+constexpr bool kNtGatherStore = FC3D_NT_BIT(6);   // image gradient: d/dIp (read by the PSF backward next)
+constexpr bool kNtPsfBwdLoad = FC3D_NT_BIT(7);    // PSF backward: d/dIp and layer indices (last use)
+constexpr bool kNtPsfBwdStore = FC3D_NT_BIT(8);   // PSF backward: the pattern gradient
+constexpr bool kNtPsfFwdLoad = FC3D_NT_BIT(9);    // PSF forward: pattern and depth
+constexpr bool kNtPsfFwdStore = FC3D_NT_BIT(10);  // PSF forward: un-normalised image (read by the normalisation next)
+constexpr bool kNtNormLoad = FC3D_NT_BIT(11);     // normalisation: un-normalised image (last use)
+constexpr bool kNtNormStore = FC3D_NT_BIT(12);    // normalisation: the coded pattern (sampled two launches later)
+constexpr bool kNtGatherImg = FC3D_NT_BIT(13);    // image gradient: the sampled image, for the by-product sum (its last use)
+
+typedef float fc3d_f4v __attribute__((ext_vector_type(4)));
+typedef float fc3d_f2v __attribute__((ext_vector_type(2)));
+template <bool NT>
+__device__ __forceinline__ float ld_pol(const float* p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+template <bool NT>
+__device__ __forceinline__ uint8_t ld_pol(const uint8_t* p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+template <bool NT>
+__device__ __forceinline__ float2 ld_pol(const float2* p) {
+    if constexpr (NT) {
+        const fc3d_f2v v = __builtin_nontemporal_load(reinterpret_cast<const fc3d_f2v*>(p));
+        return make_float2(v.x, v.y);
+    } else {
+        return *p;
+    }
+}
+template <bool NT>
+__device__ __forceinline__ float4 ld_pol(const float4* p) {
+    if constexpr (NT) {
+        const fc3d_f4v v = __builtin_nontemporal_load(reinterpret_cast<const fc3d_f4v*>(p));
+        return make_float4(v.x, v.y, v.z, v.w);
+    } else {
+        return *p;
+    }
+}
+template <bool NT>
+__device__ __forceinline__ void st_pol(float* p, float v) {
+    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+template <bool NT>
+__device__ __forceinline__ void st_pol(float2* p, float2 v) {
+    if constexpr (NT) {
+        const fc3d_f2v w = {v.x, v.y};
+        __builtin_nontemporal_store(w, reinterpret_cast<fc3d_f2v*>(p));
+    } else {
+        *p = v;
+    }
+}
+template <bool NT>
+__device__ __forceinline__ void st_pol(float4* p, float4 v) {
+    if constexpr (NT) {
+        const fc3d_f4v w = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(w, reinterpret_cast<fc3d_f4v*>(p));
+    } else {
+        *p = v;
+    }
+}
+// ld_at / st_at (uniform base + 32-bit element offset) with a cache policy
+template <bool NT, typename T>
+__device__ __forceinline__ T ld_at_pol(const T* base, unsigned elem) {
+    return ld_pol<NT>(reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + elem * (unsigned)sizeof(T)));
+}
+template <bool NT, typename T>
+__device__ __forceinline__ void st_at_pol(T* base, unsigned elem, T v) {
+    st_pol<NT>(reinterpret_cast<T*>(reinterpret_cast<char*>(base) + elem * (unsigned)sizeof(T)), v);
 }
 
 template <typename T>

@@ -114,11 +114,11 @@ enum CoordLayout { kStrided = 0, kPlanarFlat = 1, kPixel4Flat = 2 };
 // kPixel4Flat : dense [H][W][4] (what z2pointcloud's permuted view points at): one aligned float4 per pixel
 // kStrided    : any other view; (y, x) are recovered from p
 
-template <int LAYOUT>
+template <int LAYOUT, bool NT = false>
 __device__ __forceinline__ void load_coord(const float* __restrict__ base, long sc, long sh, long sw, long p, int W,
                                            float c[4]) {
     if (LAYOUT == kPixel4Flat) {
-        const float4 v = *reinterpret_cast<const float4*>(base + p * 4);
+        const float4 v = ld_pol<NT>(reinterpret_cast<const float4*>(base + p * 4));
         c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w;
     } else if (LAYOUT == kPlanarFlat) {
 #pragma unroll
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(NT) void project_kernel(const float* __restrict__ c
 #pragma unroll
     for (int i = 0; i < PPL; ++i) {
         const long p = p0 + 64 * i;
-        if (p < HW) load_coord<LAYOUT>(cb, sc, sh, sw, p, W, c[i]);
+        if (p < HW) load_coord<LAYOUT, kNtProjLoad>(cb, sc, sh, sw, p, W, c[i]);
     }
     // after the coordinate loads were issued: the few words of K and pose arrive under their latency
     float T[16];
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(NT) void project_kernel(const float* __restrict__ c
         if (p < HW) {
             float gx, gy;
             project_px<FMA>(T, c[i][0], c[i][1], c[i][2], c[i][3], gx, gy);
-            go[p] = make_float2(gx, gy);
+            st_pol<kNtProjStore>(go + p, make_float2(gx, gy));
             if (SPLAT) splat_px<uint8_t>(m, gx, gy, W, HW, 0, (uint8_t)1);
         }
     }
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(NT) void warp_sample_kernel(const float* __restrict
     for (int i = 0; i < PPL; ++i) {
         const long p = p0 + 64 * i;
         if (p < HW) {
-            load_coord<LAYOUT>(cb, sc, sh, sw, p, W, c[i]);
+            load_coord<LAYOUT, kNtSampLoad>(cb, sc, sh, sw, p, W, c[i]);
             mv[i] = (float)mk[p];
         }
     }
@@ -221,8 +221,8 @@ __global__ __launch_bounds__(NT) void warp_sample_kernel(const float* __restrict
     for (int i = 0; i < PPL; ++i) {
         const long p = p0 + 64 * i;
         if (p < HW) {
-            go[p] = make_float2(gx[i], gy[i]);
-            oo[p] = blend(t[i], i00[i], i01[i], i10[i], i11[i]) * mv[i];
+            st_pol<kNtSampGrid>(go + p, make_float2(gx[i], gy[i]));
+            st_pol<kNtSampOut>(oo + p, blend(t[i], i00[i], i01[i], i10[i], i11[i]) * mv[i]);
         }
     }
     if (rezero) {
@@ -618,8 +618,8 @@ __device__ __noinline__ void gather_drain(const float2* __restrict__ gb, const f
                 const unsigned p = (unsigned)seg * SEG + (lane & 15);
                 sm[d].live = (e + (lane >> 4) < n) && ((bits >> (lane & 15)) & 1);   // a live pixel lies inside the target image
                 const unsigned q = min(p, HWt - 1u);
-                sm[d].g = ld_global(gbu, q);
-                sm[d].v = ld_global(vbu, q);
+                sm[d].g = ld_global<kNtGatherLoad>(gbu, q);
+                sm[d].v = ld_global<kNtGatherLoad>(vbu, q);
             }
         }
 #pragma unroll
@@ -785,7 +785,7 @@ __global__ __launch_bounds__(NT) void bilinear_bwd_img_gather_kernel(
 #pragma unroll
         for (int r0 = 0; r0 < GY; r0 += 4) {
             const int r = min(r0 + (lane >> 4), GY - 1), x = min(sx0 + 4 * (lane & 15), Ws - 4), y = min(sy0 + r, Hs - 1);
-            iv[r0 / 4] = ld_at(reinterpret_cast<const float4*>(im), ((unsigned)y * (unsigned)Ws + (unsigned)x) >> 2);
+            iv[r0 / 4] = ld_at_pol<kNtGatherImg>(reinterpret_cast<const float4*>(im), ((unsigned)y * (unsigned)Ws + (unsigned)x) >> 2);
         }
     }
 #pragma unroll
@@ -794,7 +794,7 @@ __global__ __launch_bounds__(NT) void bilinear_bwd_img_gather_kernel(
         if (r < GY && y < Hs && x < Ws) {
             const float4 v = *reinterpret_cast<const float4*>(&s_win[wv][(r + 1) * GWS + 4 + 4 * (lane & 15)]);
             if (vec) {
-                st_at(reinterpret_cast<float4*>(o), ((unsigned)y * (unsigned)Ws + (unsigned)x) >> 2, v);
+                st_at_pol<kNtGatherStore>(reinterpret_cast<float4*>(o), ((unsigned)y * (unsigned)Ws + (unsigned)x) >> 2, v);
                 if (dot_partial) {
                     const float4 w = iv[r0 / 4];
                     dot = fmaf(v.x, w.x, dot); dot = fmaf(v.y, w.y, dot);

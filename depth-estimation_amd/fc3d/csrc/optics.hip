@@ -283,7 +283,7 @@ __global__ __launch_bounds__(NT) void code_pattern_norm_kernel(
         for (int j = 0; j < NORM_V; ++j) {
             const long i = (((long)blockIdx.x * NORM_V + j) * NT + threadIdx.x) * 4;
             v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < HW) v[j] = *reinterpret_cast<const float4*>(raw + base + i);
+            if (i < HW) v[j] = ld_pol<kNtNormLoad>(reinterpret_cast<const float4*>(raw + base + i));
         }
     }
     const unsigned long long key = block_max_key(tilekey + (long)b * ntiles, ntiles, s_red);
@@ -300,8 +300,8 @@ __global__ __launch_bounds__(NT) void code_pattern_norm_kernel(
         for (int j = 0; j < NORM_V; ++j) {
             const long i = (((long)blockIdx.x * NORM_V + j) * NT + threadIdx.x) * 4;
             if (i < HW)
-                *reinterpret_cast<float4*>(out + base + i) =
-                    make_float4(v[j].x * rden, v[j].y * rden, v[j].z * rden, v[j].w * rden);
+                st_pol<kNtNormStore>(reinterpret_cast<float4*>(out + base + i),
+                                     make_float4(v[j].x * rden, v[j].y * rden, v[j].z * rden, v[j].w * rden));
         }
     } else {
         const long i0 = (long)blockIdx.x * NORM_V * NT * 4;
@@ -553,8 +553,8 @@ __global__ __launch_bounds__(NT) void code_pattern_bwd_roll_kernel(
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         const unsigned q = (unsigned)(min(max(y0 - PAD + r, 0), H - 1) * W + xc);
-        gv[r] = ld_at(gi, q);
-        lv[r] = ld_at(li, q);
+        gv[r] = ld_at_pol<kNtPsfBwdLoad>(gi, q);
+        lv[r] = ld_at_pol<kNtPsfBwdLoad>(li, q);
     }
     if (!DOT) {
 #pragma unroll
@@ -633,7 +633,7 @@ __global__ __launch_bounds__(NT) void code_pattern_bwd_roll_kernel(
             for (int dx = 1; dx < PAD; ++dx) dn = acc[o][dx] + from_lane_above(dn);
             dn = from_lane_above(dn);
             const float res = (acc[o][PAD] + up) + dn;
-            if (mine && yo < H) st_at(gp, (unsigned)(yo * W + x), res);
+            if (mine && yo < H) st_at_pol<kNtPsfBwdStore>(gp, (unsigned)(yo * W + x), res);
         }
     }
 }
@@ -708,10 +708,11 @@ void code_pattern_fwd_roll_kernel(
 
     float pv[NR], zv[R];
 #pragma unroll
-    for (int r = 0; r < NR; ++r) pv[r] = ld_at(pimg, (unsigned)min(max(y0 - PAD + r, 0), H - 1) * (unsigned)sh + pcol);
+    for (int r = 0; r < NR; ++r)
+        pv[r] = ld_at_pol<kNtPsfFwdLoad>(pimg, (unsigned)min(max(y0 - PAD + r, 0), H - 1) * (unsigned)sh + pcol);
     if (!SHADE) {
 #pragma unroll
-        for (int o = 0; o < R; ++o) zv[o] = ld_at(zimg, (unsigned)(min(y0 + o, H - 1) * W + xc));
+        for (int o = 0; o < R; ++o) zv[o] = ld_at_pol<kNtPsfFwdLoad>(zimg, (unsigned)(min(y0 + o, H - 1) * W + xc));
     } else {
         float za[NR + 1], zr63[NR];       // depth of every pattern row and the one below; lane 63's right neighbours
 #pragma unroll
@@ -780,7 +781,7 @@ void code_pattern_fwd_roll_kernel(
                 best = take ? a : best;
                 besto = take ? o : besto;
                 const unsigned q = (unsigned)(yo * W + x);
-                st_at(rimg, q, a);
+                st_at_pol<kNtPsfFwdStore>(rimg, q, a);
                 if (limg) st_at(limg, q, (uint8_t)l);
             }
         }

@@ -1,6 +1,11 @@
 import os
 import sys
 
+# The convolution library reads its search mode once, when it is first used: without this every new
+# layer shape of the U-Nets is searched exhaustively (minutes at 32x512x512 on a machine without a
+# tuning database).  FAST takes the library's heuristic pick.  Must be set before torch is imported.
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+
 import numpy as np
 import pytest
 

@@ -345,9 +345,30 @@ def test_train_step_at_the_per_gpu_shard_of_the_data_parallel_config(env, monkey
     monkeypatch.setenv("MIOPEN_FIND_MODE", "FAST")       # the library's heuristic pick, not a search per layer shape
     t_start = time.time()
 
-    def progress(what):          # the first step compiles the convolution library's kernels: say that the test is alive
+    def progress(what):
         with capsys.disabled():
             print(f"[train-step test] {what} ({time.time() - t_start:.0f} s)", flush=True)
+
+    import contextlib
+    import threading
+
+    @contextlib.contextmanager
+    def alive(what):
+        """The first steps compile the convolution library's kernels, silently and for a long time on a
+        fresh machine: a line every 30 s tells a watching harness that the test is not hung."""
+        done = threading.Event()
+
+        def beat():
+            while not done.wait(30.0):
+                print(f"[train-step test] {what} ... ({time.time() - t_start:.0f} s)", flush=True)
+        with capsys.disabled():
+            th = threading.Thread(target=beat, daemon=True)
+            th.start()
+            try:
+                yield
+            finally:
+                done.set()
+                th.join()
     O, capture, synth = env["O"], env["capture"], env["synth"]
     B, H, W = 32, 512, 512
     O.PSFs_np = synth.make_psfs(21, 5, "disc")
@@ -363,7 +384,8 @@ def test_train_step_at_the_per_gpu_shard_of_the_data_parallel_config(env, monkey
     noise = capture._draw_noise(B, H, W, z_p.device)
     w0 = step.params[0].detach().clone()
     progress("networks built")
-    loss0 = float(step(z_p, z_c, pose, noise=noise))
+    with alive("first step"):
+        loss0 = float(step(z_p, z_c, pose, noise=noise))
     progress("first step done")
     cap = step.last_capture
     grads = step.bucket.flat.clone()                     # the step's gradients (the bucket is cleared only before the next backward)
@@ -380,28 +402,35 @@ def test_train_step_at_the_per_gpu_shard_of_the_data_parallel_config(env, monkey
         m.train()
     Ic_s, Ic_m, xyz, xy, zc, _zp, pose_o, _, Ic, Ip_coded, _ = alone
     inp = capture.local_norm(Ic_s, 17, 0.01)
-    xyz_hat = torch.cat([replica[0](inp), replica[1](inp)], dim=-1)
-    l_rec, *_ = capture.cal_cost(xyz, xyz_hat, Ic_m)
-    l_rep, *_ = capture.reProj_IpGT(xyz_hat[..., 2:3], pose_o, xy, Ic, zc, Ic_m, Ip_coded, intrinsics=(W / 2, H / 2))
-    loss_r = l_rec + l_rep
-    loss_r.backward()
+    with alive("replica"):
+        xyz_hat = torch.cat([replica[0](inp), replica[1](inp)], dim=-1)
+        l_rec, *_ = capture.cal_cost(xyz, xyz_hat, Ic_m)
+        l_rep, *_ = capture.reProj_IpGT(xyz_hat[..., 2:3], pose_o, xy, Ic, zc, Ic_m, Ip_coded, intrinsics=(W / 2, H / 2))
+        loss_r = l_rec + l_rep
+        loss_r.backward()
+        torch.cuda.synchronize()
     progress("replica done")
-    assert abs(float(loss_r) - loss0) <= 1e-4 * abs(loss0)
+    assert abs(float(loss_r.detach()) - loss0) <= 1e-4 * abs(loss0)
     off = 0
     worst = 0.0
-    for p in list(replica[0].parameters()) + list(replica[1].parameters()):
+    rp = list(replica[0].parameters()) + list(replica[1].parameters())
+    gmax = max(float(p.grad.abs().max()) for p in rp)
+    for p in rp:
         n = p.numel()
         got = grads[off:off + n].view_as(p)
-        scale = float(p.grad.abs().max())
-        if scale > 0:
-            worst = max(worst, float((got - p.grad).abs().max()) / scale)
+        # per tensor, on the tensor's own scale -- but not below 1e-3 of the largest gradient: a convolution bias
+        # in front of a batch norm has a gradient that is zero analytically and rounding noise numerically
+        scale = max(float(p.grad.abs().max()), 1e-3 * gmax)
+        worst = max(worst, float((got - p.grad).abs().max()) / scale)
         off += n
     assert off == grads.numel()
+    progress(f"bucket vs replica gradients: worst relative difference {worst:.2e}")
     assert worst < 2e-3, worst                            # the convolution library's weight gradients use float atomics
     del replica, xyz_hat, loss_r, inp
 
     # 3. a second step: the weights moved, the loss is finite (and Adam's first step lowers it on the same batch)
-    loss1 = float(step(z_p, z_c, pose, noise=noise))
+    with alive("second step"):
+        loss1 = float(step(z_p, z_c, pose, noise=noise))
     assert np.isfinite(loss0) and np.isfinite(loss1)
     assert not torch.equal(w0, step.params[0].detach())
     assert loss1 < loss0 * 1.05, (loss0, loss1)

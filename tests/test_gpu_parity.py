@@ -662,7 +662,10 @@ def test_reproj_chain(mods, golden, monkeypatch):
     assert rel_err(grid.detach().cpu().numpy(), g["grid"]) < 1e-5
     assert rel_err(Ic.detach().cpu().numpy(), g["Ic"]) < TOL
     assert rel_err(zp.grad.cpu().numpy(), g["grad_zp"]) < TOL
-    assert rel_err_elem(zp.grad.cpu().numpy(), g["grad_zp"]) < TOL
+    # element by element where the value is above 3 % of the scale: this gradient is a sum of two terms of the
+    # scale's size (through zc and through the sampled pattern), so a small element is their cancellation and
+    # carries the rounding noise of the large ones (measured: 5.8e-5 above 3 %, 3.7e-4 at 1e-3 of the scale)
+    assert rel_err_elem(zp.grad.cpu().numpy(), g["grad_zp"], floor=3e-2) < TOL
 
 
 def test_reproject_fused(mods, golden, monkeypatch):
@@ -691,7 +694,7 @@ def test_reproject_fused(mods, golden, monkeypatch):
     assert rel_err(Ic2.detach().cpu().numpy(), Ic1.detach().cpu().numpy()) < TOL
     ((Ic2 * dev(g["g_ic"])).sum() + (zc2 * dev(g["g_zc"])).sum()).backward()
     assert rel_err(zp2.grad.cpu().numpy(), g["grad_zp"]) < TOL
-    assert rel_err_elem(zp2.grad.cpu().numpy(), g["grad_zp"]) < TOL
+    assert rel_err_elem(zp2.grad.cpu().numpy(), g["grad_zp"], floor=3e-2) < TOL       # see test_reproj_chain
     for use in ("zc", "Ic"):
         a = dev(g["zp"]).requires_grad_(True)
         b = dev(g["zp"]).requires_grad_(True)
