@@ -50,6 +50,7 @@ __device__ __forceinline__ int layer_of(float z, const fc3d_layer_grid& g) {
 // infinite and NaN depths come out as -1 on both chains.
 struct LayerFast {
     float rstep, thr;
+    float a, nb;      // n' = a / z - b as one fused multiply-add: a = coeff / step, nb = -a * inv_z0
 };
 __device__ __forceinline__ LayerFast layer_fast_setup(const fc3d_layer_grid& g) {
     const float eps = 1.1920929e-7f;
@@ -59,15 +60,37 @@ __device__ __forceinline__ LayerFast layer_fast_setup(const fc3d_layer_grid& g) 
     LayerFast f;
     f.rstep = 1.0f / g.step;
     f.thr = 4.0f * eps * (1.5f * gain * rmax + 3.0f * nmax);   // NaN/inf for a degenerate grid: everything is redone exactly
+    f.a = g.coeff * f.rstep;
+    f.nb = -(f.a * g.inv_z0);
     return f;
 }
+// The host's promise behind INTC0: centre0 is an integer (|centre0| < 2^22).  Then rr - centre0 is exact, the
+// layer is that difference itself, and the third test of layer_of, |rr - (centre0 + l)| < 0.01, always holds.
+static inline bool layer_grid_centre_is_integer(const fc3d_layer_grid& g) {
+    return g.centre0 == rintf(g.centre0) && fabsf(g.centre0) < 4194304.0f;
+}
+template <bool INTC0 = false>
 __device__ __forceinline__ int layer_fast(float z, const fc3d_layer_grid& g, const LayerFast& f, bool& ambiguous) {
     const float r = __builtin_amdgcn_rcpf(z);
-    const float d = r - g.inv_z0;
-    const float wm = g.coeff * d;
-    const float n = wm * f.rstep;
+    float n;
+    if (INTC0) {
+        // One fused multiply-add for subtraction and both scalings.  With N the real-number value and G = coeff/step:
+        // |n - N| <= eps (1.5 G |1/z| + 1.5 |N|) (one ulp of the reciprocal, the roundings of a, nb and of the fused
+        // operation itself), and the exact chain's quotient is within eps (0.5 G |1/z| + 1.5 |N|) of N: together
+        // inside f.thr, which allows eps (6 G |1/z| + 12 |N|).
+        n = fmaf(r, f.a, f.nb);
+    } else {
+        const float d = r - g.inv_z0;
+        const float wm = g.coeff * d;
+        n = wm * f.rstep;
+    }
     const float rr = rintf(n);
     ambiguous = !(fabsf(n - rr) <= 0.5f - f.thr) && (fabsf(n) < 1.0e9f);
+    if (INTC0) {
+        const float lf = rr - g.centre0;
+        const bool ok = (lf >= 0.0f) && (lf < (float)g.n_layers);
+        return ok ? (int)lf : -1;
+    }
     const float lf = rintf(rr - g.centre0);
     const bool ok = (lf >= 0.0f) && (lf < (float)g.n_layers) && (fabsf(rr - (g.centre0 + lf)) < 0.01f);
     return ok ? (int)lf : -1;
@@ -479,12 +502,28 @@ __device__ __forceinline__ void lds_read4(const float* p, float (&dst)[N]) {
 #ifndef FC3D_SHADE_WAVES
 #define FC3D_SHADE_WAVES 5
 #endif
+#ifndef FC3D_ROLL_PK
+#define FC3D_ROLL_PK 1       // packed multiply-adds in the rolling-row kernels (tuning switch)
+#endif
+#ifndef FC3D_ROLL_ORDER
+#define FC3D_ROLL_ORDER 1    // PSF loads ahead of the image loads, image loads in the order the rows are consumed (tuning switch)
+#endif
+typedef float f2 __attribute__((ext_vector_type(2)));
+// acc + w * (v.x, v.x): a packed multiply-add whose second operand takes its low half for both lanes of the pair
+// (op_sel_hi), so that a value shared by both products needs no copy into a register pair of its own per use.
+__device__ __forceinline__ f2 pk_fma_lo(f2 w, f2 v, f2 acc) {
+    f2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(w), "v"(v), "v"(acc));
+    return r;
+}
 template <int K>
 struct Roll {
     static constexpr int PAD = (K - 1) / 2;
     static constexpr int SW = 64 - (K - 1);      // output columns per strip
     static constexpr int KK = K * K;
-    static constexpr int KKP = (KK + 3) & ~3;    // one layer's PSF, padded to whole float4s
+    static constexpr int KS = K + 1;             // floats per PSF row in LDS and registers: even, so that the pairs a
+                                                 // packed multiply-add takes (columns 0-1, 2-3, ...) start on even registers
+    static constexpr int KKP = (K * KS + 3) & ~3;   // one layer's PSF, padded to whole float4s
     static constexpr int FWD_WAVES = K <= 5 ? 6 : 3;   // wavefronts per SIMD the forward kernel is compiled for
     static constexpr int FWD_WAVES_SHADE = K <= 5 ? FC3D_SHADE_WAVES : 3;   // ... with the shading folded in (a depth value per pattern row more)
 };
@@ -497,12 +536,55 @@ __device__ __forceinline__ float from_lane_above(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));   // wave_shl:1
 }
 
+// The PSF stack in two halves: its (cache-resident) global loads are issued FIRST, ahead of a strip's image
+// loads -- loads return in issue order, so behind them the weights would only be usable once every image
+// row had arrived, and every wavefront would sit through the whole memory latency before its first
+// multiply-add -- and the values go to LDS after the image loads have been issued.
+constexpr int kPsfStageMax = 8;      // staged floats per thread: L * KKP <= 8 * NT, else the plain loop below
+template <int K>
+struct PsfStage {
+    float v[kPsfStageMax];
+};
+template <int K>
+__device__ __forceinline__ bool psf_stage_fits(int L) { return L * Roll<K>::KKP <= kPsfStageMax * NT; }
+template <int K>
+__device__ __forceinline__ void psf_stage_load(PsfStage<K>& st, const float* __restrict__ psf, int L) {
+    constexpr int KK = Roll<K>::KK, KKP = Roll<K>::KKP, KS = Roll<K>::KS;
+    // unconditional loads from clamped (always valid) addresses: no branch, no wait between them
+#pragma unroll
+    for (int u = 0; u < kPsfStageMax; ++u) {
+        const int i = min(u * NT + (int)threadIdx.x, L * KKP - 1);
+        const int l = i / KKP, j = i - l * KKP;
+        const int dy = j / KS, dx = j - dy * KS;
+        st.v[u] = ld_at(psf, (unsigned)(l * KK + min(dy, K - 1) * K + min(dx, K - 1)));
+    }
+}
+template <int K>
+__device__ __forceinline__ void psf_stage_store(const PsfStage<K>& st, float* __restrict__ wts, int L) {
+    constexpr int KKP = Roll<K>::KKP;
+#pragma unroll
+    for (int u = 0; u < kPsfStageMax; ++u) {
+        const int i = u * NT + threadIdx.x;
+        const int j = i % KKP;
+        const bool pad = (j / Roll<K>::KS >= K) || (j % Roll<K>::KS >= K);     // the padding of a row / of the layer
+        if (i < L * KKP) wts[i] = pad ? 0.0f : st.v[u];
+    }
+}
+// a * b for wave-uniform a on the scalar unit, opaque to the compiler: folded into the lane arithmetic that
+// follows, the product became a 64-bit vector multiply-add whose unused upper input register was the target of
+// a load in flight, and the wavefront waited for that load before it could issue its own
+__device__ __forceinline__ int scalar_mul(int a, int b) {
+    int r;
+    asm("s_mul_i32 %0, %1, %2" : "=s"(r) : "s"(a), "s"(b));
+    return r;
+}
 template <int K>
 __device__ __forceinline__ void stage_psf_stack(float* __restrict__ wts, const float* __restrict__ psf, int L) {
-    constexpr int KK = Roll<K>::KK, KKP = Roll<K>::KKP;
+    constexpr int KK = Roll<K>::KK, KKP = Roll<K>::KKP, KS = Roll<K>::KS;
     for (int i = threadIdx.x; i < L * KKP; i += NT) {
         const int l = i / KKP, j = i - l * KKP;
-        wts[i] = j < KK ? psf[l * KK + j] : 0.0f;
+        const int dy = j / KS, dx = j - dy * KS;
+        wts[i] = (dy < K && dx < K) ? psf[l * KK + dy * K + dx] : 0.0f;
     }
 }
 
@@ -524,7 +606,7 @@ __global__ __launch_bounds__(NT) void code_pattern_bwd_roll_kernel(
     const float* __restrict__ max_in, const float* __restrict__ psf, int H, int W, int L, int nstrips,
     float* __restrict__ partial, float* __restrict__ g_pat0, const int* __restrict__ argmax_in,
     const float* __restrict__ dot_partial, int ndot) {
-    constexpr int PAD = Roll<K>::PAD, SW = Roll<K>::SW, KKP = Roll<K>::KKP;
+    constexpr int PAD = Roll<K>::PAD, SW = Roll<K>::SW, KKP = Roll<K>::KKP, KS = Roll<K>::KS;
     constexpr int NR = R + K - 1;                 // source rows a strip reads
     extern __shared__ float smem[];               // [L][KKP]
     const int b = blockIdx.y;
@@ -536,7 +618,7 @@ __global__ __launch_bounds__(NT) void code_pattern_bwd_roll_kernel(
     const int wid = __builtin_amdgcn_readfirstlane(block_x() * (NT / 64) + wv);   // the same for all lanes: keep it scalar
     const long pidx = (long)b * (gridDim.x * (NT / 64)) + wid;
     const int strip = wid % nstrips;
-    const int xs = strip * SW;                    // first output column of this wavefront's strip
+    const int xs = scalar_mul(strip, SW);         // first output column of this wavefront's strip
     const int x = xs - PAD + lane;
     const int y0 = (wid / nstrips) * R;
     const bool colok = x >= 0 && x < W;
@@ -546,10 +628,14 @@ __global__ __launch_bounds__(NT) void code_pattern_bwd_roll_kernel(
     const float* oi = out + img;
     float* gp = g_pat0 + img;
 
-    // every source row up front, from clamped (always valid) addresses, and before the PSF stack
-    // is staged: one memory latency per strip, overlapped with the staging
+    // every source row up front, from clamped (always valid) addresses, in the order the rows are
+    // consumed and behind the (cache-resident) PSF stack: one memory latency per strip
     float gv[NR], ov[R];
     int lv[NR];
+    const bool staged = FC3D_ROLL_ORDER && psf_stage_fits<K>(L);     // the same in every thread of the launch
+    PsfStage<K> pst;
+    __builtin_amdgcn_sched_barrier(0);      // see the forward kernel
+    if (staged) psf_stage_load<K>(pst, psf, L);
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         const unsigned q = (unsigned)(min(max(y0 - PAD + r, 0), H - 1) * W + xc);
@@ -577,7 +663,8 @@ __global__ __launch_bounds__(NT) void code_pattern_bwd_roll_kernel(
             sfix = (colok && x == px) ? sp : 0.0f;
         }
     }
-    stage_psf_stack<K>(smem, psf, L);
+    if (staged) psf_stage_store<K>(pst, smem, L);
+    else stage_psf_stack<K>(smem, psf, L);
     __syncthreads();
     if (y0 >= H) {
         if (!DOT && lane == 0) partial[pidx] = 0.0f;
@@ -597,11 +684,27 @@ __global__ __launch_bounds__(NT) void code_pattern_bwd_roll_kernel(
     lds_read4<KKP>(smem, w);
     // acc[o][dx]: what this lane's pixels send to output row o, column x + dx - pad.  The sideways
     // hand-over waits until the row is complete: K-1 shifts per output row, not per source row.
+    // Columns 0-1, 2-3, ... are pairs: one packed multiply-add (two per lane and instruction) serves both.
+#if FC3D_ROLL_PK
+    f2 accp[R][K / 2];
+    float accl[R];
+#pragma unroll
+    for (int o = 0; o < R; ++o) {
+#pragma unroll
+        for (int j = 0; j < K / 2; ++j) accp[o][j] = f2{0.0f, 0.0f};
+        accl[o] = 0.0f;
+    }
+    auto acc_at = [&](int o, int dx) -> float {
+        return dx == K - 1 ? accl[o] : ((dx & 1) ? accp[o][dx >> 1].y : accp[o][dx >> 1].x);
+    };
+#else
     float acc[R][K];
 #pragma unroll
     for (int o = 0; o < R; ++o)
 #pragma unroll
         for (int dx = 0; dx < K; ++dx) acc[o][dx] = 0.0f;
+    auto acc_at = [&](int o, int dx) -> float { return acc[o][dx]; };
+#endif
 
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
@@ -609,6 +712,9 @@ __global__ __launch_bounds__(NT) void code_pattern_bwd_roll_kernel(
         const bool ok = colok && y >= 0 && y < H && lv[r] != 255;
         const float gsrc = DOT ? gv[r] - (y == py ? sfix : 0.0f) : gv[r];
         const float v = ok ? gsrc * rden : 0.0f;
+#if FC3D_ROLL_PK
+        const f2 vv = {v, 0.0f};                  // only the low half is read (pk_fma_lo)
+#endif
         const int l = ok ? lv[r] : lcur;          // pixels that contribute nothing keep the weights they have
         if (__ballot(l != lcur) != 0ull) {
             lds_read4<KKP>(smem + l * KKP, w);
@@ -618,21 +724,28 @@ __global__ __launch_bounds__(NT) void code_pattern_bwd_roll_kernel(
         for (int dy = 0; dy < K; ++dy) {
             const int o = r + dy - 2 * PAD;       // output row (from y0) fed by source row r through PSF row dy
             if (o < 0 || o >= R) continue;
+#if FC3D_ROLL_PK
 #pragma unroll
-            for (int dx = 0; dx < K; ++dx) acc[o][dx] = fmaf(w[dy * K + dx], v, acc[o][dx]);
+            for (int j = 0; j < K / 2; ++j)
+                accp[o][j] = pk_fma_lo(f2{w[dy * KS + 2 * j], w[dy * KS + 2 * j + 1]}, vv, accp[o][j]);
+            accl[o] = fmaf(w[dy * KS + K - 1], v, accl[o]);      // K is odd
+#else
+#pragma unroll
+            for (int dx = 0; dx < K; ++dx) acc[o][dx] = fmaf(w[dy * KS + dx], v, acc[o][dx]);
+#endif
         }
         if (r >= 2 * PAD) {
             const int o = r - 2 * PAD;            // complete: its last source row was this one
             const int yo = y0 + o;
-            float up = acc[o][K - 1];             // travels to higher lanes, one column per step
+            float up = acc_at(o, K - 1);          // travels to higher lanes, one column per step
 #pragma unroll
-            for (int dx = K - 2; dx > PAD; --dx) up = acc[o][dx] + from_lane_below(up);
+            for (int dx = K - 2; dx > PAD; --dx) up = acc_at(o, dx) + from_lane_below(up);
             up = from_lane_below(up);
-            float dn = acc[o][0];                 // travels to lower lanes
+            float dn = acc_at(o, 0);              // travels to lower lanes
 #pragma unroll
-            for (int dx = 1; dx < PAD; ++dx) dn = acc[o][dx] + from_lane_above(dn);
+            for (int dx = 1; dx < PAD; ++dx) dn = acc_at(o, dx) + from_lane_above(dn);
             dn = from_lane_above(dn);
-            const float res = (acc[o][PAD] + up) + dn;
+            const float res = (acc_at(o, PAD) + up) + dn;
             if (mine && yo < H) st_at_pol<kNtPsfBwdStore>(gp, (unsigned)(yo * W + x), res);
         }
     }
@@ -676,14 +789,14 @@ __global__ __launch_bounds__(NT) void code_pattern_bwd_max_kernel(
 // (withReflectance, utils_pytorch.py:251-280, then codePattern: train_pytorch.py:91-94), so that the shaded
 // pattern never goes through memory: the depth is loaded for every pattern row of the strip plus the row
 // below, the right neighbour comes from the next lane (lane 63 loads its own).
-template <int K, int R, bool SHADE = false>
+template <int K, int R, bool SHADE = false, bool INTC0 = false>
 __global__ __launch_bounds__(NT)
 __attribute__((amdgpu_waves_per_eu(SHADE ? Roll<K>::FWD_WAVES_SHADE : Roll<K>::FWD_WAVES, SHADE ? Roll<K>::FWD_WAVES_SHADE : Roll<K>::FWD_WAVES)))
 void code_pattern_fwd_roll_kernel(
     const float* __restrict__ pat0, long sb, long sh, long sw, const float* __restrict__ z,
     const float* __restrict__ psf, int H, int W, int nstrips, fc3d_layer_grid lg, float* __restrict__ raw,
     uint8_t* __restrict__ layer_u8, unsigned long long* __restrict__ tilekey) {
-    constexpr int PAD = Roll<K>::PAD, SW = Roll<K>::SW, KKP = Roll<K>::KKP;
+    constexpr int PAD = Roll<K>::PAD, SW = Roll<K>::SW, KKP = Roll<K>::KKP, KS = Roll<K>::KS;
     constexpr int NR = R + K - 1;
     extern __shared__ float smem[];               // [L][KKP]
     const int b = blockIdx.y;
@@ -693,7 +806,7 @@ void code_pattern_fwd_roll_kernel(
     const int wid = __builtin_amdgcn_readfirstlane(block_x() * (NT / 64) + wv);
     const long kidx = (long)b * (gridDim.x * (NT / 64)) + wid;
     const int strip = wid % nstrips;
-    const int xs = strip * SW;
+    const int xs = scalar_mul(strip, SW);
     const int x = xs - PAD + lane;
     const int y0 = (wid / nstrips) * R;
     const bool colok = x >= 0 && x < W;
@@ -707,13 +820,26 @@ void code_pattern_fwd_roll_kernel(
     const unsigned pcol = (unsigned)xc * (unsigned)sw;
 
     float pv[NR], zv[R];
-#pragma unroll
-    for (int r = 0; r < NR; ++r)
-        pv[r] = ld_at_pol<kNtPsfFwdLoad>(pimg, (unsigned)min(max(y0 - PAD + r, 0), H - 1) * (unsigned)sh + pcol);
+    const bool staged = FC3D_ROLL_ORDER && psf_stage_fits<K>(lg.n_layers);     // the same in every thread of the launch
+    PsfStage<K> pst;
+    __builtin_amdgcn_sched_barrier(0);      // the index arithmetic above stays above: hoisted over it, the PSF loads' target
+                                            // registers got reused by it and the strip's own loads waited a round trip
+    if (staged) psf_stage_load<K>(pst, psf, lg.n_layers);
+    auto ld_p = [&](int r) {
+        return ld_at_pol<kNtPsfFwdLoad>(pimg, (unsigned)min(max(y0 - PAD + r, 0), H - 1) * (unsigned)sh + pcol);
+    };
     if (!SHADE) {
+        // in the order the rows are consumed: output row o needs pattern rows up to o + K - 1 and depth row o
 #pragma unroll
-        for (int o = 0; o < R; ++o) zv[o] = ld_at_pol<kNtPsfFwdLoad>(zimg, (unsigned)(min(y0 + o, H - 1) * W + xc));
+        for (int r = 0; r < K - 1; ++r) pv[r] = ld_p(r);
+#pragma unroll
+        for (int o = 0; o < R; ++o) {
+            pv[o + K - 1] = ld_p(o + K - 1);
+            zv[o] = ld_at_pol<kNtPsfFwdLoad>(zimg, (unsigned)(min(y0 + o, H - 1) * W + xc));
+        }
     } else {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) pv[r] = ld_p(r);
         float za[NR + 1], zr63[NR];       // depth of every pattern row and the one below; lane 63's right neighbours
 #pragma unroll
         for (int r = 0; r <= NR; ++r) za[r] = ld_at(zimg, (unsigned)(min(max(y0 - PAD + r, 0), H - 1) * W + xc));
@@ -732,7 +858,8 @@ void code_pattern_fwd_roll_kernel(
         for (int o = 0; o < R; ++o) zv[o] = za[o + PAD];
     }
     const LayerFast lfast = layer_fast_setup(lg);
-    stage_psf_stack<K>(smem, psf, lg.n_layers);   // after the loads above were issued: the latencies overlap
+    if (staged) psf_stage_store<K>(pst, smem, lg.n_layers);
+    else stage_psf_stack<K>(smem, psf, lg.n_layers);
     __syncthreads();
     if (y0 >= H) {
         if (lane == 0) tilekey[kidx] = 0ull;      // below every real key
@@ -762,7 +889,7 @@ void code_pattern_fwd_roll_kernel(
             const int yo = y0 + o;
             const bool inb = mine && yo < H;
             bool amb;
-            int l = layer_fast(zv[o], lg, lfast, amb);
+            int l = layer_fast<INTC0>(zv[o], lg, lfast, amb);
             if (__ballot(amb && inb) != 0ull) l = layer_of(zv[o], lg);   // rare: the exact chain for the whole row
             l = inb ? l : -1;
             const int lw = l >= 0 ? l : lcur;
@@ -771,10 +898,30 @@ void code_pattern_fwd_roll_kernel(
                 lcur = lw;
             }
             float a = 0.0f;
+#if FC3D_ROLL_PK
+            // packed multiply-adds: columns 0-1, 2-3, ... of a PSF row as pairs (even and odd partial sums), the
+            // last column on its own; dy ascending within each
+            // (one accumulator per column pair: a packed multiply-add that reads the result of the one before
+            // it waits a state)
+            f2 a2[K / 2];
+#pragma unroll
+            for (int j = 0; j < K / 2; ++j) a2[j] = f2{0.0f, 0.0f};
+#pragma unroll
+            for (int dy = 0; dy < K; ++dy) {
+#pragma unroll
+                for (int j = 0; j < K / 2; ++j)
+                    a2[j] = __builtin_elementwise_fma(f2{w[dy * KS + 2 * j], w[dy * KS + 2 * j + 1]},
+                                                      f2{win[o + dy][2 * j], win[o + dy][2 * j + 1]}, a2[j]);
+                a = fmaf(w[dy * KS + K - 1], win[o + dy][K - 1], a);      // K is odd
+            }
+#pragma unroll
+            for (int j = 0; j < K / 2; ++j) a += a2[j].x + a2[j].y;
+#else
 #pragma unroll
             for (int dy = 0; dy < K; ++dy)
 #pragma unroll
-                for (int dx = 0; dx < K; ++dx) a = fmaf(w[dy * K + dx], win[o + dy][dx], a);
+                for (int dx = 0; dx < K; ++dx) a = fmaf(w[dy * KS + dx], win[o + dy][dx], a);
+#endif
             a = a * (l >= 0 ? 1.0f : 0.0f);       // a multiply: a non-finite blur still poisons the pixel
             if (inb) {
                 const bool take = (a > best) || (a != a && best == best);
@@ -1003,8 +1150,6 @@ constexpr int kSweepCols = FC3D_SWEEP_COLS;       // output columns per wavefron
 constexpr int kSweepRows = FC3D_SWEEP_ROWS;       // output rows per lane
 constexpr int kSweepTileRows = (64 / kSweepCols) * kSweepRows;
 #define FC3D_FOR_SWEEP_K(X) X(9) X(11) X(13) X(15) X(17) X(19) X(21) X(23) X(25) X(27) X(29) X(31) X(33)
-
-typedef float f2 __attribute__((ext_vector_type(2)));
 
 // Packed multiply-adds (v_pk_fma_f32: two per lane and instruction): a PSF row is consumed in pairs
 // of neighbouring columns, even and odd partial sums added at the end.  Measured per PSF size at
@@ -1513,11 +1658,13 @@ extern "C" int fc3d_code_pattern_fwd(void* stream, const float* pat0, int64_t pa
 #define FC3D_FWD_ROLL_CASE(KV)                                                                                   \
     if (Kw == KV) {                                                                                              \
         const size_t rlds = (size_t)grid.n_layers * Roll<KV>::KKP * sizeof(float);                               \
-        if (int e = allow_big_lds(code_pattern_fwd_roll_kernel<KV, RR>, rlds)) return e;                  \
+        auto kern = layer_grid_centre_is_integer(grid) ? code_pattern_fwd_roll_kernel<KV, RR, false, true>       \
+                                                       : code_pattern_fwd_roll_kernel<KV, RR, false, false>;     \
+        if (int e = allow_big_lds(kern, rlds)) return e;                                                         \
         const int nstrips = cdiv(W, Roll<KV>::SW);                                                               \
         const dim3 gr(cdiv((long)nstrips * cdiv(H, RR), NT / 64), B);                                            \
         *keys_per_image = (int)(gr.x * (NT / 64));                                                               \
-        FC3D_LAUNCH("code_pattern_fwd", (code_pattern_fwd_roll_kernel<KV, RR>), gr, blk, rlds, s, pat0,          \
+        FC3D_LAUNCH("code_pattern_fwd", kern, gr, blk, rlds, s, pat0,                                            \
                     (long)pat_sb, (long)pat_sh, (long)pat_sw, z, psf, H, W, nstrips, grid, raw_out, layer_u8,    \
                     (unsigned long long*)tilekey_u64);                                                           \
         return FC3D_OK;                                                                                          \
@@ -1582,11 +1729,13 @@ extern "C" int fc3d_code_pattern_shaded_conv_fwd(void* stream, const float* pat0
 #define FC3D_FWD_SHADE_CASE(KV)                                                                                  \
     if (Kw == KV) {                                                                                              \
         const size_t rlds = (size_t)grid.n_layers * Roll<KV>::KKP * sizeof(float);                               \
-        if (int e = allow_big_lds(code_pattern_fwd_roll_kernel<KV, RR, true>, rlds)) return e;                   \
+        auto kern = layer_grid_centre_is_integer(grid) ? code_pattern_fwd_roll_kernel<KV, RR, true, true>        \
+                                                       : code_pattern_fwd_roll_kernel<KV, RR, true, false>;      \
+        if (int e = allow_big_lds(kern, rlds)) return e;                                                         \
         const int nstrips = cdiv(W, Roll<KV>::SW);                                                               \
         const dim3 gr(cdiv((long)nstrips * cdiv(H, RR), NT / 64), B);                                            \
         *keys_per_image = (int)(gr.x * (NT / 64));                                                               \
-        FC3D_LAUNCH("code_pattern_shaded_fwd", (code_pattern_fwd_roll_kernel<KV, RR, true>), gr, blk, rlds, s,   \
+        FC3D_LAUNCH("code_pattern_shaded_fwd", kern, gr, blk, rlds, s,                                           \
                     pat0, (long)pat_sb, (long)pat_sh, (long)pat_sw, z, psf, H, W, nstrips, grid, raw_out,        \
                     layer_u8, (unsigned long long*)tilekey_u64);                                                 \
         return FC3D_OK;                                                                                          \
