@@ -74,6 +74,14 @@ def parse():
                     help="graph launch only: put warp_p2c's projection + splat launch beside codePattern on a second "
                          "branch of the graph instead of behind it (measured 2-4 us per step slower: the fork and "
                          "join cost more than the overlap of the two kernels gives)")
+    ap.add_argument("--unroll", type=int, default=0,
+                    help="graph launch: consecutive steps held by the graph that is replayed in the timed region "
+                         "(0 = automatic, see main)")
+    ap.add_argument("--settle", type=int, default=100,
+                    help="untimed steps issued right before the W warm-up steps, through the same launch path as the timed "
+                         "ones and without a pause in between: the per-kernel event pass and the copy yardstick that run "
+                         "before them leave gaps of milliseconds in which the GPU's clocks fall back, and W = 5 steps "
+                         "(1 ms) do not bring them up again")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--n1-value", type=float, default=None,
@@ -290,6 +298,10 @@ def main():
         # ... that also divides W, so that the warm-up steps run the very graph (and touch the very buffers)
         # that the timed steps use
         unroll = max(u for u in range(1, 11) if args.steps % u == 0 and (args.warmup <= 0 or args.warmup % u == 0))
+        if args.unroll > 0:
+            if args.steps % args.unroll:
+                sys.exit("--unroll must divide --steps")
+            unroll = args.unroll
         try:
             gf = GraphedImageFormation(tens["pat"], tens["z_p"], tens["coord_p"], tens["coord_c"], tens["pose"],
                                        tens["g"], tens["L"], unroll=unroll, overlap=args.overlap)
@@ -317,6 +329,11 @@ def main():
     profiler.enable(False)
     copy_rate = copy_bandwidth(device)
 
+    settle = 0
+    if args.settle > 0:
+        per_launch = int(launch.split("x")[1].split(",")[0]) if launch.startswith("hip_graph") else 1
+        settle = -(-args.settle // per_launch) * per_launch          # whole launches of the timed graph
+        run_steps(settle)
     if args.warmup > 0:
         run_steps(args.warmup)
     barrier()
@@ -388,7 +405,7 @@ def main():
             "value": value, "unit": "captures/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "ms_per_step_graph_x1": ms_graph_x1, "ms_per_step_eager": ms_eager,
+            "ms_per_step_graph_x1": ms_graph_x1, "ms_per_step_eager": ms_eager, "settle_steps": settle,
             **scaling_fields(args, value, world, dist.get_world_size() if dist is not None else 1, per_rank),
             "config": {"workload": f"{args.workload}: {B}x{H}x{W} per GPU, L={cfg['L']} depth layers, "
                                    f"{cfg['K']}x{cfg['K']} '{args.psf_kind}' PSFs, pose theta<={cfg['theta_deg']}deg; "

@@ -600,6 +600,9 @@ struct GatherTile {
     float fbx0, fbx1, fby0, fby1;     // base cells whose taps reach the tile
     float fcol0;                      // source column of window column 0
 };
+#ifndef FC3D_GATHER_PIPE
+#define FC3D_GATHER_PIPE 0        // 1: two batches of sample loads in flight, the second issued before the first batch is added (measured slower: 46.6-53 against 45.5 us, registers)
+#endif
 __device__ __noinline__ void gather_drain(const float2* __restrict__ gb, const float* __restrict__ vb, unsigned HWt,
                                           lds_vfloat win, lds_vu8 own, lds_vint cand, lds_vint cbits, int n,
                                           GatherTile tl) {
@@ -607,8 +610,8 @@ __device__ __noinline__ void gather_drain(const float2* __restrict__ gb, const f
     const int lane = threadIdx.x & 63;
     const auto gbu = uniform_global(gb);
     const auto vbu = uniform_global(vb);
-    for (int e0 = 0; e0 < n; e0 += STEP * G_DEPTH) {
-        GatherSample sm[G_DEPTH];
+    // the loads of one batch: G_DEPTH steps of STEP segments each
+    auto issue = [&](GatherSample (&sm)[G_DEPTH], int e0) {
 #pragma unroll
         for (int d = 0; d < G_DEPTH; ++d) {
             const int e = e0 + d * STEP;
@@ -622,6 +625,9 @@ __device__ __noinline__ void gather_drain(const float2* __restrict__ gb, const f
                 sm[d].v = ld_global<kNtGatherLoad>(vbu, q);
             }
         }
+    };
+    // ... and their taps into the window
+    auto consume = [&](GatherSample (&sm)[G_DEPTH], int e0) {
 #pragma unroll
         for (int d = 0; d < G_DEPTH; ++d) {
             if (e0 + d * STEP < n) {
@@ -639,7 +645,24 @@ __device__ __noinline__ void gather_drain(const float2* __restrict__ gb, const f
 #endif
             }
         }
+    };
+    constexpr int BATCH = STEP * G_DEPTH;
+#if FC3D_GATHER_PIPE
+    GatherSample a[G_DEPTH], b[G_DEPTH];
+    issue(a, 0);
+    for (int e0 = 0; e0 < n; e0 += 2 * BATCH) {
+        issue(b, e0 + BATCH);
+        consume(a, e0);
+        issue(a, e0 + 2 * BATCH);
+        consume(b, e0 + BATCH);
     }
+#else
+    for (int e0 = 0; e0 < n; e0 += BATCH) {
+        GatherSample sm[G_DEPTH];
+        issue(sm, e0);
+        consume(sm, e0);
+    }
+#endif
 }
 
 #ifdef FC3D_GATHER_WAVES
