@@ -67,6 +67,9 @@ SIGNATURES = {
     "fc3d_reproj_loss_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "fc3d_zp_to_zc_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
     "fc3d_zp_to_zc_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
+    "fc3d_zp_to_zc_bwd_full_workspace": (c_size_t, [c_int, c_int, c_int]),
+    "fc3d_zp_to_zc_bwd_full": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P, P, P, P]),
+    "fc3d_points_bwd_rays": (c_int, [P, P, P, c_int, c_int, c_int, P]),
     "fc3d_reflectance_fwd": (c_int, [P, P, I64, P, c_int, c_int, c_int, P]),
     "fc3d_capture_warp_fwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, P, P, P, c_int, P, P]),
     "fc3d_capture_post_workspace": (c_size_t, [c_int, c_int, c_int]),

@@ -7,6 +7,7 @@ that it travels with the source tree; nothing is installed.
 """
 from __future__ import annotations
 
+import hashlib
 import os
 import shutil
 import subprocess
@@ -32,12 +33,34 @@ def _hipcc() -> str:
     return exe
 
 
+STAMP = LIB + ".stamp"      # sha256 of what the library was built from (sources, header, flags, compiler version)
+
+
+def source_hash(extra_flags=()) -> str:
+    """sha256 over every file of csrc/, include/fc3d.h, the compiler flags and the compiler's version string."""
+    h = hashlib.sha256()
+    for path in sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)) + [os.path.join(ROOT, "include", "fc3d.h")]:
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join([*FLAGS, *extra_flags, *SOURCES]).encode())
+    try:
+        h.update(subprocess.run([_hipcc(), "--version"], capture_output=True, timeout=60).stdout)
+    except Exception:
+        pass
+    return h.hexdigest()
+
+
 def needs_build() -> bool:
-    if not os.path.exists(LIB):
+    """True unless the library exists AND was produced from exactly the current sources, header and flags
+    (a hash stored beside it; file times say nothing once a tree has been copied or checked out)."""
+    if not (os.path.exists(LIB) and os.path.exists(STAMP)):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "fc3d.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    try:
+        with open(STAMP) as f:
+            return f.read().strip() != source_hash()
+    except OSError:
+        return True
 
 
 def build(force: bool = False, verbose: bool = True, extra_flags=(), out: str = LIB) -> str:
@@ -49,6 +72,9 @@ def build(force: bool = False, verbose: bool = True, extra_flags=(), out: str = 
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    if out == LIB:
+        with open(STAMP, "w") as f:
+            f.write(source_hash(extra_flags) + "\n")
     return out
 
 

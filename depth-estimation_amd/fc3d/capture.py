@@ -186,39 +186,64 @@ def forward_model(z_p, z_c, pose_p2c, n_layers=21, is_conv_psf=True, crop=None, 
     return (c(Ic_scaled), c(Ic_mask), c(xyz_cView), c(xy), c(z_c), c(z_p), pose_p2c, z_p, c(Ic), Ip_coded, Ic_scaled)
 
 
+def _per_crop(t, B_sub):
+    """pose / pattern of B samples for B_sub crops of each: the reference's .repeat(B_sub, ...) order
+    (train_pytorch.py:198, :202), i.e. crop i belongs to sample i % B."""
+    return t if B_sub == 1 else t.repeat(B_sub, *([1] * (t.dim() - 1)))
+
+
+def _crops_per_sample(zp, pose_p2c):
+    B_all, B = zp.shape[0], pose_p2c.shape[0]
+    if B == 0 or B_all % B:
+        raise ValueError(f"{B_all} depth maps for {B} poses: the number of maps must be a multiple of the number of samples")
+    return B_all // B
+
+
 def reproject(zp, pose_p2c, xy, IpGT, fused=True, intrinsics=None):
     """(zc, Ic_reProj) of the re-projection chain, train_pytorch.py:194-202: camera-view projector
     depth -> camera depth -> scene points -> projector pixel -> sampled pattern.  fused=True runs
-    the chain as one kernel per direction (gradient w.r.t. zp only); fused=False composes the
-    drop-in operators as the reference does (also differentiable w.r.t. IpGT).  intrinsics: of the
-    full-size image IpGT (zp and xy may be crops of it)."""
+    the chain as one kernel per direction when only zp asks for a gradient; otherwise (or with
+    fused=False) the drop-in operators are composed as the reference does, which differentiates
+    everything the reference's autograd does: zp, pose, xy and IpGT.  zp / xy may hold B_sub crops
+    per sample (zp.shape[0] = B_sub * pose.shape[0], :189-191).  intrinsics: of the full-size image
+    IpGT (zp and xy may be crops of it)."""
     from . import ops
-    K = resolve_intrinsics(intrinsics, zp.shape[0], IpGT.shape[1], IpGT.shape[2], zp.device)
-    if fused and not (torch.is_grad_enabled() and (xy.requires_grad or IpGT.requires_grad or pose_p2c.requires_grad)):
-        _, T_c2p, pose_c2p = ops.pose_transforms(pose_p2c.detach(), K, want_inv=True, want_a=True)
-        return ops.ReprojectFn.apply(zp, xy, pose_c2p, T_c2p, IpGT)
-    zc = G.zp_cView_to_zc(zp, pose_p2c, xy)
+    B_sub = _crops_per_sample(zp, pose_p2c)
+    B_all = zp.shape[0]
+    K = resolve_intrinsics(intrinsics, B_all, IpGT.shape[1], IpGT.shape[2], zp.device)
+    grads_elsewhere = torch.is_grad_enabled() and (xy.requires_grad or IpGT.requires_grad or pose_p2c.requires_grad)
+    if fused and not grads_elsewhere:
+        _, T_c2p, pose_c2p = ops.pose_transforms(_per_crop(pose_p2c.detach(), B_sub), K, want_inv=True, want_a=True)
+        return ops.ReprojectFn.apply(zp, xy, pose_c2p, T_c2p, _per_crop(IpGT, B_sub))
+    if B_sub > 1 and pose_p2c.shape[0] > 1:
+        zc = G.zp_cView_to_zc(zp, _per_crop(pose_p2c, B_sub), xy)        # the reference's own call only broadcasts one pose
+    else:
+        zc = G.zp_cView_to_zc(zp, pose_p2c, xy)
     ray = torch.cat([xy, torch.ones_like(zc)], dim=-1)
     coord_c = G.points_in_camera_coords(zc, ray, allBatch=True).permute(0, 3, 1, 2)
-    # inverse(pose) once, through the library's own kernel, as a detached constant
-    _, _, pose_c2p = ops.pose_transforms(pose_p2c.detach(), None, want_a=True)
-    grid_c2p = G._coord0TOgrid1(coord_c, pose_c2p, K)
-    return zc, G.bilinear_sampler(IpGT, grid_c2p)
+    if torch.is_grad_enabled() and pose_p2c.requires_grad:
+        pose_c2p = ops.PoseInverseFn.apply(pose_p2c)
+    else:          # inverse(pose) once, through the library's own kernel, as a constant
+        _, _, pose_c2p = ops.pose_transforms(pose_p2c.detach(), None, want_a=True)
+    grid_c2p = G._coord0TOgrid1(coord_c, _per_crop(pose_c2p, B_sub), K)
+    return zc, G.bilinear_sampler(_per_crop(IpGT, B_sub), grid_c2p)
 
 
 def reProj_IpGT(zp_cView, pose_p2c, xy, Ic, zcGT, maskC, IpGT, fused=True, intrinsics=None, reduce=None):
-    """Re-projection loss; train_pytorch.py:179-211 (one crop per sample).  fused=True: erosion,
-    chain, masked sums and the scalar arithmetic of the losses run in the loss kernels (gradient
-    w.r.t. zp_cView only).  reduce: None, or a callable applied to the masked sums and the mask
-    count before the losses are formed (fc3d.dist.sum_over_ranks: the losses of the global batch)."""
+    """Re-projection loss; train_pytorch.py:179-211, B_sub crops per sample included (:189-202).  fused=True:
+    erosion, chain, masked sums and the scalar arithmetic of the losses run in the loss kernels when only
+    zp_cView asks for a gradient; anything else that does goes through the composed operators.  reduce: None,
+    or a callable applied to the masked sums and the mask count before the losses are formed
+    (fc3d.dist.sum_over_ranks: the losses of the global batch)."""
     me = erode(maskC, 5)
     grads_elsewhere = torch.is_grad_enabled() and any(
         t.requires_grad for t in (pose_p2c, xy, Ic, zcGT, maskC, IpGT))
     if fused and zp_cView.is_cuda and zp_cView.shape[0] > 0 and not grads_elsewhere:
         from . import ops
+        B_sub = _crops_per_sample(zp_cView, pose_p2c)
         K = resolve_intrinsics(intrinsics, zp_cView.shape[0], IpGT.shape[1], IpGT.shape[2], zp_cView.device)
-        _, T_c2p, pose_c2p = ops.pose_transforms(pose_p2c.detach(), K, want_inv=True, want_a=True)
-        L = ops.ReprojLossFn.apply(zp_cView, me, xy, pose_c2p, T_c2p, IpGT, Ic, zcGT,
+        _, T_c2p, pose_c2p = ops.pose_transforms(_per_crop(pose_p2c.detach(), B_sub), K, want_inv=True, want_a=True)
+        L = ops.ReprojLossFn.apply(zp_cView, me, xy, pose_c2p, T_c2p, _per_crop(IpGT, B_sub), Ic, zcGT,
                                    None if reduce is None else (lambda s: reduce(s).detach()))
         return L[0], L[1], L[2], L[3]
     zp = zp_cView * me

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(NT) void capture_sample_kernel(const float* __restr
         const long p = p0 + 64 * i;
         gn[i] = 0.0f;
         if (p < HW) {
-            z[i] = zb[p];
+            z[i] = ld_pol<kNtCapDepth>(zb + p);
             mv[i] = (float)mk[p];
             if (peak_partial) gn[i] = gauss[(long)b * HW + p];
         }
@@ -212,9 +212,9 @@ __global__ __launch_bounds__(NT) void capture_sample_kernel(const float* __restr
             const float icv = __fmul_rn(blend(t[i], i00[i], i01[i], i10[i], i11[i]), mv[i]);
             peak = max_nan(peak, exposed(icv, off005, gn[i]));
             oo[p] = icv;
-            xo[p * 3 + 0] = __fmul_rn(blend(t[i], rx0[i], rx0[i], rx1[i], rx1[i]), mv[i]);
-            xo[p * 3 + 1] = __fmul_rn(blend(t[i], ry0[i], ry1[i], ry0[i], ry1[i]), mv[i]);
-            xo[p * 3 + 2] = __fmul_rn(blend(t[i], z00[i], z01[i], z10[i], z11[i]), mv[i]);
+            st_pol<kNtCapXyz>(xo + p * 3 + 0, __fmul_rn(blend(t[i], rx0[i], rx0[i], rx1[i], rx1[i]), mv[i]));
+            st_pol<kNtCapXyz>(xo + p * 3 + 1, __fmul_rn(blend(t[i], ry0[i], ry1[i], ry0[i], ry1[i]), mv[i]));
+            st_pol<kNtCapXyz>(xo + p * 3 + 2, __fmul_rn(blend(t[i], z00[i], z01[i], z10[i], z11[i]), mv[i]));
         }
     }
     if (peak_partial) {
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(NT) void capture_sensor_kernel(const float* __restr
     if (VEC == 4) {
         for (long p = lo + 4L * threadIdx.x; p < hi; p += 4L * NT) {
             const float4 a = *reinterpret_cast<const float4*>(ic + p);
-            const float4 n = *reinterpret_cast<const float4*>(g + p);
+            const float4 n = ld_pol<kNtCapNoise>(reinterpret_cast<const float4*>(g + p));
             const uchar4 v = *reinterpret_cast<const uchar4*>(mk + p);
             if (rezero) *reinterpret_cast<uchar4*>(mk + p) = make_uchar4(0, 0, 0, 0);
             float4 s, w;
@@ -310,8 +310,8 @@ __global__ __launch_bounds__(NT) void capture_sensor_kernel(const float* __restr
             sensor_px(a.y, off005, n.y, peak, gain, (float)v.y, s.y, w.y);
             sensor_px(a.z, off005, n.z, peak, gain, (float)v.z, s.z, w.z);
             sensor_px(a.w, off005, n.w, peak, gain, (float)v.w, s.w, w.w);
-            *reinterpret_cast<float4*>(so + p) = s;
-            *reinterpret_cast<float4*>(mo + p) = w;
+            st_pol<kNtCapOut>(reinterpret_cast<float4*>(so + p), s);
+            st_pol<kNtCapOut>(reinterpret_cast<float4*>(mo + p), w);
         }
     } else {
         for (long p = lo + threadIdx.x; p < hi; p += NT) {

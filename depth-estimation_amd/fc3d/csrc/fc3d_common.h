@@ -143,6 +143,10 @@ constexpr bool kNtPsfFwdStore = FC3D_NT_BIT(10);  // PSF forward: un-normalised 
 constexpr bool kNtNormLoad = FC3D_NT_BIT(11);     // normalisation: un-normalised image (last use)
 constexpr bool kNtNormStore = FC3D_NT_BIT(12);    // normalisation: the coded pattern (sampled two launches later)
 constexpr bool kNtGatherImg = FC3D_NT_BIT(13);    // image gradient: the sampled image, for the by-product sum (its last use)
+constexpr bool kNtCapDepth = FC3D_NT_BIT(14);     // capture, inverse warp: the camera's depth map (read once)
+constexpr bool kNtCapXyz = FC3D_NT_BIT(15);       // capture, inverse warp: the camera-view scene coordinates
+constexpr bool kNtCapNoise = FC3D_NT_BIT(16);     // capture, sensor model: the read-noise plane (its last use)
+constexpr bool kNtCapOut = FC3D_NT_BIT(17);       // capture, sensor model: the scaled capture and its validity mask
 
 typedef float fc3d_f4v __attribute__((ext_vector_type(4)));
 typedef float fc3d_f2v __attribute__((ext_vector_type(2)));

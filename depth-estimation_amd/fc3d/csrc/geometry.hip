@@ -952,6 +952,81 @@ __global__ __launch_bounds__(NT) void zp_to_zc_bwd_kernel(const float* __restric
     g_zp[q] = g_zc[q] / zc_den(a, r.x, r.y);
 }
 
+// d zc / d (zp, xy, inverse pose): with q = g / den and t = -q * zc,
+//   g_zp = q,   g_x = t * a20,   g_y = t * a21,
+//   g_A[2][0..3] = sum over the sample's pixels of (t x, t y, t, -q); every other entry of g_A is zero.
+// The four sums leave the kernel as one partial per workgroup; zc_grad_sum_kernel adds them in a fixed order.
+__global__ __launch_bounds__(NT) void zp_to_zc_bwd_full_kernel(const float* __restrict__ g_zc, const float* __restrict__ zc,
+                                                               const float* __restrict__ xy, const float* __restrict__ inv,
+                                                               long HW, float* __restrict__ g_zp, float* __restrict__ g_xy,
+                                                               float4* __restrict__ partial) {
+    __shared__ float4 sh[NT / 64];
+    const int b = blockIdx.y;
+    const long p = (long)blockIdx.x * NT + threadIdx.x;
+    const float* a = inv + (long)b * 16;
+    float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (p < HW) {
+        const long q = (long)b * HW + p;
+        const float2 r = *reinterpret_cast<const float2*>(xy + q * 2);
+        const float qq = g_zc[q] / zc_den(a, r.x, r.y);
+        const float t = -(qq * zc[q]);
+        if (g_zp) g_zp[q] = qq;
+        if (g_xy) *reinterpret_cast<float2*>(g_xy + q * 2) = make_float2(t * a[8], t * a[9]);
+        s = make_float4(t * r.x, t * r.y, t, -qq);
+    }
+    if (partial) {
+        s.x = wave_sum(s.x); s.y = wave_sum(s.y); s.z = wave_sum(s.z); s.w = wave_sum(s.w);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float4 t4 = sh[0];
+#pragma unroll
+            for (int w = 1; w < NT / 64; ++w) { t4.x += sh[w].x; t4.y += sh[w].y; t4.z += sh[w].z; t4.w += sh[w].w; }
+            partial[(long)b * gridDim.x + blockIdx.x] = t4;
+        }
+    }
+}
+
+// g_A [B][16]: row 2 = the sums of the partials (fixed order, double accumulators), the rest zero.
+__global__ __launch_bounds__(NT) void zc_grad_sum_kernel(const float4* __restrict__ partial, int nblk, float* __restrict__ g_inv) {
+    __shared__ double s_red[NT / 64][4];
+    const int b = blockIdx.x;
+    const float4* pb = partial + (long)b * nblk;
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int i = threadIdx.x; i < nblk; i += NT) {
+        const float4 v = pb[i];
+        s[0] += (double)v.x; s[1] += (double)v.y; s[2] += (double)v.z; s[3] += (double)v.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s[k] += __shfl_xor(s[k], o, 64);
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6][k] = s[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        float v = 0.0f;
+        if (threadIdx.x >= 8 && threadIdx.x < 12) {
+            double t = s_red[0][threadIdx.x - 8];
+            for (int w = 1; w < NT / 64; ++w) t += s_red[w][threadIdx.x - 8];
+            v = (float)t;
+        }
+        g_inv[(long)b * 16 + threadIdx.x] = v;
+    }
+}
+
+// d points / d rays for per-sample ray maps (points_in_camera_coords with allBatch): g_ray = g_out[..., 0:3] * z
+__global__ __launch_bounds__(NT) void points_bwd_rays_kernel(const float* __restrict__ g_out, const float* __restrict__ z,
+                                                             long n, float* __restrict__ g_ray) {
+    const long q = (long)blockIdx.x * NT + threadIdx.x;
+    if (q >= n) return;
+    const float4 g = *reinterpret_cast<const float4*>(g_out + q * 4);
+    const float zz = z[q];
+    g_ray[q * 3 + 0] = g.x * zz;
+    g_ray[q * 3 + 1] = g.y * zz;
+    g_ray[q * 3 + 2] = g.z * zz;
+}
+
 // ---------------------------------------------------------------------------------------
 // Fused re-projection (the differentiated chain of reProj_IpGT, train_pytorch.py:194-202):
 //   zc    = (zp - A[2][3]) / (A[2][0] x + A[2][1] y + A[2][2])           zp_cView_to_zc, A = inverse(pose)
@@ -1661,6 +1736,38 @@ extern "C" int fc3d_zp_to_zc_bwd(void* stream, const float* g_zc, const float* x
     FC3D_LAUNCH("zp_to_zc_bwd", zp_to_zc_bwd_kernel, dim3(cdiv(HW, NT), B), dim3(NT), 0, (hipStream_t)stream, g_zc, xy, inv, HW,
                        g_zp);
     FC3D_LAUNCH_CHECK();
+    return FC3D_OK;
+}
+
+extern "C" size_t fc3d_zp_to_zc_bwd_full_workspace(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)B * cdiv((long)H * W, NT) * sizeof(float4);
+}
+
+extern "C" int fc3d_zp_to_zc_bwd_full(void* stream, const float* g_zc, const float* zc, const float* xy, const float* inv,
+                                      int B, int H, int W, float* g_zp, float* g_xy, void* workspace, float* g_inv) {
+    if (!g_zc || !zc || !xy || !inv || (!g_zp && !g_xy && !g_inv) || (g_inv && !workspace)) return FC3D_EINVAL;
+    if (int e = check_img(B, H, W)) return e;
+    if ((reinterpret_cast<uintptr_t>(xy) & 7u) || (g_xy && (reinterpret_cast<uintptr_t>(g_xy) & 7u)) ||
+        (workspace && !aligned16(workspace)))
+        return FC3D_EALIGN;
+    const long HW = (long)H * W;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 g(cdiv(HW, NT), B);
+    float4* partial = g_inv ? (float4*)workspace : nullptr;
+    FC3D_LAUNCH("zp_to_zc_bwd_full", zp_to_zc_bwd_full_kernel, g, dim3(NT), 0, s, g_zc, zc, xy, inv, HW, g_zp, g_xy, partial);
+    if (g_inv)
+        FC3D_LAUNCH("zc_grad_sum", zc_grad_sum_kernel, dim3(B), dim3(NT), 0, s, (const float4*)partial, (int)g.x, g_inv);
+    return FC3D_OK;
+}
+
+extern "C" int fc3d_points_bwd_rays(void* stream, const float* g_out, const float* z, int B, int H, int W, float* g_ray) {
+    if (!g_out || !z || !g_ray) return FC3D_EINVAL;
+    if (int e = check_img(B, H, W)) return e;
+    if (!aligned16(g_out)) return FC3D_EALIGN;
+    const long n = (long)B * H * W;
+    FC3D_LAUNCH("points_bwd_rays", points_bwd_rays_kernel, dim3(cdiv(n, NT)), dim3(NT), 0, (hipStream_t)stream, g_out, z, n,
+                g_ray);
     return FC3D_OK;
 }
 

@@ -659,22 +659,21 @@ class WarpSampleFn(torch.autograd.Function):
 
 
 class PointsFn(torch.autograd.Function):
-    """points_in_camera_coords; geometry_pytorch.py:44-65.  Returns [B,H,W,4].
-    Differentiable in z_map only: the rays are constants of the camera in the reference
-    (numpy arrays, geometry_pytorch.py:54-57), and rays that require a gradient are refused
-    rather than silently given none."""
+    """points_in_camera_coords; geometry_pytorch.py:44-65.  Returns [B,H,W,4].  Differentiable in z_map and
+    in the rays (per-sample ray maps as reProj_IpGT builds them from xy, train_pytorch.py:196-197; a
+    shared table or the separable form get the sums over what they were broadcast over)."""
 
     @staticmethod
     def forward(ctx, z_map, ray_x, ray_y, ray_dense):
         dev = _need_gpu(z_map, ray_x, ray_y, ray_dense)
-        if any(ctx.needs_input_grad[1:]):
-            raise NotImplementedError("points_in_camera_coords: no gradient w.r.t. the rays; detach them")
         if z_map.dim() != 4 or z_map.shape[-1] != 1:
             raise RuntimeError(f"z_map must be [B,H,W,1], got {tuple(z_map.shape)}")
         z = _dense(z_map)
         B, H, W, _ = z.shape
         sb = 0
+        dense_shape = None
         if ray_dense is not None:
+            dense_shape = tuple(ray_dense.shape)
             ray_dense = _dense(ray_dense)
             if tuple(ray_dense.shape[-3:]) != (H, W, 3):
                 raise RuntimeError(f"The size of tensor a ({W}) must match the size of tensor b "
@@ -688,25 +687,58 @@ class PointsFn(torch.autograd.Function):
         with _on_device(dev):
             _check(_lib.fc3d_points_fwd(_stream(), z.data_ptr(), ptr(ray_x), ptr(ray_y), ptr(ray_dense), sb, B, H, W,
                                         out.data_ptr()), "fc3d_points_fwd")
-        ctx.save_for_backward(ray_x, ray_y, ray_dense)
-        ctx.shape = (B, H, W, sb)
+        ray_grad = any(ctx.needs_input_grad[1:])
+        ctx.save_for_backward(ray_x, ray_y, ray_dense, z if ray_grad else None)
+        ctx.shape = (B, H, W, sb, dense_shape)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
-        ray_x, ray_y, ray_dense = ctx.saved_tensors
-        B, H, W, sb = ctx.shape
+        ray_x, ray_y, ray_dense, z = ctx.saved_tensors
+        B, H, W, sb, dense_shape = ctx.shape
         g = _dense(g_out)
-        gz = torch.empty((B, H, W, 1), dtype=torch.float32, device=g.device)
+        gz = g_rx = g_ry = g_rd = None
         ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
         with _on_device(g.device):
-            _check(_lib.fc3d_points_bwd(_stream(), g.data_ptr(), ptr(ray_x), ptr(ray_y), ptr(ray_dense), sb, B, H, W,
-                                        gz.data_ptr()), "fc3d_points_bwd")
-        return gz, None, None, None
+            if ctx.needs_input_grad[0]:
+                gz = torch.empty((B, H, W, 1), dtype=torch.float32, device=g.device)
+                _check(_lib.fc3d_points_bwd(_stream(), g.data_ptr(), ptr(ray_x), ptr(ray_y), ptr(ray_dense), sb, B, H, W,
+                                            gz.data_ptr()), "fc3d_points_bwd")
+            if any(ctx.needs_input_grad[1:]):
+                gr = torch.empty((B, H, W, 3), dtype=torch.float32, device=g.device)       # per sample and pixel
+                _check(_lib.fc3d_points_bwd_rays(_stream(), g.data_ptr(), z.data_ptr(), B, H, W, gr.data_ptr()),
+                       "fc3d_points_bwd_rays")
+                if ray_dense is not None and ctx.needs_input_grad[3]:
+                    # a table shared by the batch collects the sum over the samples it was broadcast to
+                    g_rd = gr if sb else gr.sum(0, keepdim=len(dense_shape) == 4)
+                    g_rd = g_rd.reshape(dense_shape)
+                if ray_dense is None:
+                    if ctx.needs_input_grad[1]:
+                        g_rx = gr[..., 0].sum((0, 1)).reshape(ray_x.shape)
+                    if ctx.needs_input_grad[2]:
+                        g_ry = gr[..., 1].sum((0, 2)).reshape(ray_y.shape)
+        return gz, g_rx, g_ry, g_rd
+
+
+class PoseInverseFn(torch.autograd.Function):
+    """inverse(pose) [B,4,4] (fp64 Gauss-Jordan, rounded once) with its gradient -A^T g_A A^T."""
+
+    @staticmethod
+    def forward(ctx, pose):
+        _, _, a = pose_transforms(pose, None, want_a=True)
+        ctx.save_for_backward(a)
+        return a
+
+    @staticmethod
+    def backward(ctx, g_a):
+        a, = ctx.saved_tensors
+        at = a.transpose(1, 2)
+        return -(at @ g_a @ at)
 
 
 class ZpToZcFn(torch.autograd.Function):
-    """zp_cView_to_zc given inverse(pose); geometry_pytorch.py:284-308."""
+    """zp_cView_to_zc given inverse(pose); geometry_pytorch.py:284-308.  Differentiable in zp, xy and the
+    inverse pose (PoseInverseFn carries that on to the pose)."""
 
     @staticmethod
     def forward(ctx, zp, xy, inv):
@@ -714,26 +746,38 @@ class ZpToZcFn(torch.autograd.Function):
         B, H, W, _ = zp.shape
         if tuple(xy.shape) != (B, H, W, 2) or tuple(inv.shape) != (B, 4, 4):
             raise RuntimeError(f"zp_cView_to_zc: zp {tuple(zp.shape)}, xy {tuple(xy.shape)}, pose {tuple(inv.shape)}")
-        z, r = _dense(zp), _dense(xy)
+        z, r, a = _dense(zp), _dense(xy), _dense(inv)
         out = torch.empty_like(z)
         with _on_device(dev):
-            _check(_lib.fc3d_zp_to_zc_fwd(_stream(), z.data_ptr(), r.data_ptr(), inv.data_ptr(), B, H, W,
+            _check(_lib.fc3d_zp_to_zc_fwd(_stream(), z.data_ptr(), r.data_ptr(), a.data_ptr(), B, H, W,
                                           out.data_ptr()), "fc3d_zp_to_zc_fwd")
-        ctx.save_for_backward(r, inv)
+        full = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        ctx.save_for_backward(r, a, out if full else None)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        r, inv = ctx.saved_tensors
-        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            raise NotImplementedError("zp_cView_to_zc: only the gradient w.r.t. zp_cView is implemented")
+        r, inv, zc = ctx.saved_tensors
         B, H, W, _ = r.shape
         g = _dense(g)
-        gz = torch.empty_like(g)
-        with _on_device(g.device):
-            _check(_lib.fc3d_zp_to_zc_bwd(_stream(), g.data_ptr(), r.data_ptr(), inv.data_ptr(), B, H, W,
-                                          gz.data_ptr()), "fc3d_zp_to_zc_bwd")
-        return gz, None, None
+        dev = g.device
+        if zc is None:
+            gz = torch.empty_like(g)
+            with _on_device(dev):
+                _check(_lib.fc3d_zp_to_zc_bwd(_stream(), g.data_ptr(), r.data_ptr(), inv.data_ptr(), B, H, W,
+                                              gz.data_ptr()), "fc3d_zp_to_zc_bwd")
+            return gz, None, None
+        gz = torch.empty_like(g) if ctx.needs_input_grad[0] else None
+        gxy = torch.empty_like(r) if ctx.needs_input_grad[1] else None
+        ginv = ws = None
+        if ctx.needs_input_grad[2]:
+            ginv = torch.empty((B, 4, 4), dtype=torch.float32, device=dev)
+            ws = torch.empty(_lib.fc3d_zp_to_zc_bwd_full_workspace(B, H, W) // 4, dtype=torch.float32, device=dev)
+        ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+        with _on_device(dev):
+            _check(_lib.fc3d_zp_to_zc_bwd_full(_stream(), g.data_ptr(), zc.data_ptr(), r.data_ptr(), inv.data_ptr(), B, H, W,
+                                               ptr(gz), ptr(gxy), ptr(ws), ptr(ginv)), "fc3d_zp_to_zc_bwd_full")
+        return gz, gxy, ginv
 
 
 class ReprojectFn(torch.autograd.Function):
@@ -764,8 +808,9 @@ class ReprojectFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_zc, g_out):
-        if any(ctx.needs_input_grad[1:]):
-            raise NotImplementedError("reproject: only the gradient w.r.t. zp_cView is implemented")
+        # the one-kernel chain differentiates the depth only; fc3d.capture.reproject routes calls whose pose, xy
+        # or pattern ask for a gradient to the composed operators, which provide all of them
+        assert not any(ctx.needs_input_grad[1:]), "use fc3d.capture.reproject: it composes the operators for these gradients"
         if g_zc is None and g_out is None:
             return None, None, None, None, None
         zc, r, a, t, im = ctx.saved_tensors
@@ -825,8 +870,8 @@ class ReprojLossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_losses):
-        if any(ctx.needs_input_grad[1:]):
-            raise NotImplementedError("reproj_loss: only the gradient w.r.t. the predicted depth is implemented")
+        # as for ReprojectFn: fc3d.capture.reProj_IpGT composes the operators when anything but the depth asks
+        assert not any(ctx.needs_input_grad[1:]), "use fc3d.capture.reProj_IpGT: it composes the operators for these gradients"
         sums, z, m, r, a, t, im, ic, zg = ctx.saved_tensors
         B, H, W, _ = z.shape
         g = _dense(g_losses.to(torch.float32))

@@ -12,9 +12,9 @@ Differences a caller can observe:
     in fp32, so grids that involve the inverse can differ in the last bit;
   * bilinear_sampler indexes with integers; the reference builds flat indices
     in fp32, which goes wrong once B*H*W exceeds 2**24 (B > 64 at 512x512);
-  * the gradient w.r.t. the pose is implemented for coord_transform,
-    coord0TOgrid1 and warp_p2c; zp_cView_to_zc raises NotImplementedError for
-    it, and intrinsics are constants as in the reference.
+  * gradients: everything the reference's autograd differentiates -- images, coordinates, depths, rays
+    (per-sample maps), the pose through coord_transform, coord0TOgrid1, warp_p2c and zp_cView_to_zc (xy
+    too); the intrinsic matrix is a constant as in the reference.
 """
 from __future__ import annotations
 
@@ -229,9 +229,18 @@ def warp_p2c_finish(Ip, coord_c, begun):
 def zp_cView_to_zc(zp_cView, pose_p2c, xy):
     """Projector-frame depth seen from the camera -> camera-frame depth
     (geometry_pytorch.py:284-308)."""
-    if pose_p2c.requires_grad and torch.is_grad_enabled():
-        raise NotImplementedError("zp_cView_to_zc: gradient w.r.t. the pose is not implemented")
     if zp_cView.shape[0] == 0:
         return zp_cView.clone()
-    _, _, inv = _ops.pose_transforms(pose_p2c.detach(), None, want_a=True)
+    if pose_p2c.requires_grad and torch.is_grad_enabled():
+        inv = _ops.PoseInverseFn.apply(pose_p2c)
+    else:
+        _, _, inv = _ops.pose_transforms(pose_p2c.detach(), None, want_a=True)
+    B = zp_cView.shape[0]
+    if inv.shape[0] != B:
+        # the reference's expression broadcasts [B,1,1,1] pose entries against the maps (:301-306): one pose for
+        # several maps (reProj_IpGT with B_sub crops of one sample, train_pytorch.py:189-194) is the case that works
+        if inv.shape[0] != 1:
+            raise RuntimeError(f"The size of tensor a ({inv.shape[0]}) must match the size of tensor b ({B}) at "
+                               "non-singleton dimension 0")
+        inv = inv.expand(B, 4, 4)
     return _ops.ZpToZcFn.apply(zp_cView, xy, inv)

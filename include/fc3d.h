@@ -278,6 +278,21 @@ int fc3d_zp_to_zc_fwd(void *stream, const float *zp, const float *xy, const floa
 int fc3d_zp_to_zc_bwd(void *stream, const float *g_zc, const float *xy, const float *inv, int B, int H, int W,
                       float *g_zp);
 
+/* The whole backward of zp_cView_to_zc (the reference's expression, geometry_pytorch.py:294-306, is
+ * differentiable in all three arguments): from g_zc and the forward result zc,
+ *   g_zp [B][H][W], g_xy [B][H][W][2] and g_inv [B][16], the gradient w.r.t. inverse(pose) (row 2 holds the
+ * four per-sample sums, the other rows are zero; the gradient w.r.t. the pose itself follows through the
+ * inverse: -A^T g_A A^T).  Any of the three may be NULL; g_inv needs workspace of
+ * fc3d_zp_to_zc_bwd_full_workspace bytes, 16-byte aligned (one partial per 256 pixels, added in a fixed order). */
+size_t fc3d_zp_to_zc_bwd_full_workspace(int B, int H, int W);
+int fc3d_zp_to_zc_bwd_full(void *stream, const float *g_zc, const float *zc, const float *xy, const float *inv,
+                           int B, int H, int W, float *g_zp, float *g_xy, void *workspace, float *g_inv);
+
+/* Backward of points_in_camera_coords w.r.t. a per-sample ray map (allBatch, geometry_pytorch.py:57-63, the
+ * form reProj_IpGT calls with rays built from xy, train_pytorch.py:196-197): g_ray [B][H][W][3] =
+ * g_out[..., 0:3] * z.                                                                            */
+int fc3d_points_bwd_rays(void *stream, const float *g_out, const float *z, int B, int H, int W, float *g_ray);
+
 /* The differentiated chain of reProj_IpGT, train_pytorch.py:194-202, in one pass:
  * zc = zp_cView_to_zc(zp, pose, xy) (geometry_pytorch.py:284-308), scene points
  * (zc*x, zc*y, zc, 1) (:44-65, allBatch), grid = coord0TOgrid1(points, inverse(pose))

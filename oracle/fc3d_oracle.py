@@ -272,14 +272,17 @@ def image_formation(pattern, z_p, coord_p, coord_c, pose_p2c, psfs, cx, cy, is_c
 
 def reproject_chain(zp_cView, pose_p2c, xy, IpGT, cx, cy, pose_c2p=None):
     """zp -> zc -> scene points -> projector pixel -> sampled pattern; the
-    differentiable part of reProj_IpGT, train_pytorch.py:194-202 (B_sub=1)."""
+    differentiable part of reProj_IpGT, train_pytorch.py:189-202.  zp_cView / xy may hold B_sub maps per
+    sample: the inverse pose and the pattern are then repeated (:198, :202), and zp_cView_to_zc broadcasts
+    the pose the way its own expression does (one sample only, geometry_pytorch.py:301-306)."""
     if pose_c2p is None:
         pose_c2p = torch.linalg.inv(pose_p2c)
+    B_sub = zp_cView.shape[0] // pose_p2c.shape[0]
     zc = zp_cView_to_zc(zp_cView, pose_p2c, xy, pose_c2p)
     ray = torch.cat([xy, torch.ones_like(zc)], dim=-1)
     coord_c = points_in_camera_coords(zc, ray, allBatch=True).permute(0, 3, 1, 2)
-    grid_c2p = coord0TOgrid1(coord_c, pose_c2p, cx, cy)
-    return zc, grid_c2p, bilinear_sampler(IpGT, grid_c2p)
+    grid_c2p = coord0TOgrid1(coord_c, pose_c2p.repeat(B_sub, 1, 1), cx, cy)
+    return zc, grid_c2p, bilinear_sampler(IpGT.repeat(B_sub, 1, 1, 1), grid_c2p)
 
 
 # --------------------------------------------------------------------------- #

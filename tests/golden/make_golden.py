@@ -315,6 +315,51 @@ def g7_reproj(G):
          g_ic=g_ic, g_zc=g_zc, grad_zp=zpt.grad, cx=np.array(W / 2), cy=np.array(H / 2))
 
 
+def g11_reproj_grads(G):
+    """The re-projection chain (train_pytorch.py:194-202 written out with the reference's geometry functions) with
+    EVERY input asking for a gradient -- predicted depth, pose, xy, pattern -- and, second case, several crops per
+    sample (B_sub = 2 with B = 1: the pose is broadcast, the inverse pose and the pattern are repeated, :198, :202)."""
+    B, H, W = 2, 48, 64
+    sc, rays = small_scene(B, H, W, 81)
+    rs = np.random.RandomState(82)
+    xy = np.broadcast_to(rays[None, :, :, 0:2], (B, H, W, 2)).astype(np.float32).copy()
+    zp = (sc["z_c"] + rs.uniform(-0.004, 0.004, sc["z_c"].shape)).astype(np.float32)
+    IpGT = rs.uniform(0, 1, (B, H, W, 1)).astype(np.float32)
+    g_ic = rs.uniform(-1, 1, (B, H, W, 1)).astype(np.float32)
+    g_zc = rs.uniform(-1, 1, (B, H, W, 1)).astype(np.float32)
+    orig = G.get_intrinsic
+    G.get_intrinsic = patched_intrinsic(G, W / 2, H / 2)
+    out = dict(zp=zp, xy=xy, pose=sc["pose_p2c"], IpGT=IpGT, g_ic=g_ic, g_zc=g_zc, cx=np.array(W / 2), cy=np.array(H / 2))
+    try:
+        def chain(zpt, poset, xyt, imgt, B_sub):
+            zc = G.zp_cView_to_zc(zpt, poset, xyt)
+            ones = torch.ones(zpt.shape[0], H, W, 1)
+            ray = torch.cat([xyt, ones], dim=-1)
+            coord_c = G.points_in_camera_coords(zc, ray, allBatch=True).permute(0, 3, 1, 2)
+            pose_c2p = torch.linalg.inv(poset).repeat(B_sub, 1, 1)
+            grid = G.coord0TOgrid1(coord_c, pose_c2p)
+            return zc, G.bilinear_sampler(imgt.repeat(B_sub, 1, 1, 1), grid)
+        leaves = [t(a).clone().requires_grad_(True) for a in (zp, sc["pose_p2c"], xy, IpGT)]
+        zc, Ic = chain(*leaves, 1)
+        ((Ic * t(g_ic)).sum() + (zc * t(g_zc)).sum()).backward()
+        out.update(zc=zc, Ic=Ic, pose_c2p=torch.linalg.inv(t(sc["pose_p2c"])), grad_zp=leaves[0].grad, grad_pose=leaves[1].grad,
+                   grad_xy=leaves[2].grad, grad_IpGT=leaves[3].grad)
+        # only zc used: the gradient of zp_cView_to_zc alone
+        leaves = [t(a).clone().requires_grad_(True) for a in (zp, sc["pose_p2c"], xy)]
+        (G.zp_cView_to_zc(*leaves) * t(g_zc)).sum().backward()
+        out.update(zc_only_grad_zp=leaves[0].grad, zc_only_grad_pose=leaves[1].grad, zc_only_grad_xy=leaves[2].grad)
+        # B_sub = 2, B = 1: two crops (here: two different depth predictions and ray maps) of sample 0
+        leaves = [t(zp).clone().requires_grad_(True), t(sc["pose_p2c"][0:1]).clone().requires_grad_(True),
+                  t(xy).clone().requires_grad_(True), t(IpGT[0:1]).clone().requires_grad_(True)]
+        zc2, Ic2 = chain(*leaves, 2)
+        ((Ic2 * t(g_ic)).sum() + (zc2 * t(g_zc)).sum()).backward()
+        out.update(sub_zc=zc2, sub_Ic=Ic2, sub_pose_c2p=torch.linalg.inv(t(sc["pose_p2c"][0:1])), sub_grad_zp=leaves[0].grad,
+                   sub_grad_pose=leaves[1].grad, sub_grad_xy=leaves[2].grad, sub_grad_IpGT=leaves[3].grad)
+    finally:
+        G.get_intrinsic = orig
+    save("g11_reproj_grads", **out)
+
+
 def g8_utils(U):
     """The producers and post-processing around the path, from the reference's utils_pytorch:
     dotArray pattern, withReflectance, ln, the masked losses (values and gradients)."""
@@ -487,6 +532,9 @@ def main():
     if args.only == "g9":
         g9_callers(args.ref)
         return
+    if args.only == "g11":
+        g11_reproj_grads(G)
+        return
     if args.only == "g10":
         import network_pytorch as N
         assert N.__file__.startswith(args.ref)
@@ -500,6 +548,7 @@ def main():
     g5_visible(G)
     g6_warp(G)
     g7_reproj(G)
+    g11_reproj_grads(G)
     import utils_pytorch as U
     assert U.__file__.startswith(args.ref)
     g8_utils(U)

@@ -418,6 +418,23 @@ def test_capture_data_shards(tmp_path):
     assert np.array_equal(first["z_p"].numpy(), sc["z_p"][:3]) and np.array_equal(first["pose_p2c"].numpy(), sc["pose_p2c"][:3])
 
 
+def test_library_is_rebuilt_when_sources_change_not_when_times_do(tmp_path, monkeypatch):
+    """The build check compares a hash of the sources, the header and the flags with the one stored beside
+    the library when it was built: file times play no part (a copied or checked-out tree has arbitrary ones)."""
+    from fc3d import build
+    if not os.path.exists(build.STAMP):
+        pytest.skip("library was not built through fc3d.build in this tree")
+    assert not build.needs_build()
+    os.utime(os.path.join(build.CSRC, "optics.hip"))              # newer than the library now: still up to date
+    assert not build.needs_build()
+    h = build.source_hash()
+    assert h == open(build.STAMP).read().strip() and h != build.source_hash(("-DFC3D_NT=0",))
+    monkeypatch.setattr(build, "STAMP", str(tmp_path / "other.stamp"))
+    assert build.needs_build()                                     # no record of what the library was built from
+    (tmp_path / "other.stamp").write_text("0" * 64 + "\n")
+    assert build.needs_build()                                     # built from something else
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     """No fallback: without the shared library the binding refuses to load."""
     from fc3d import _native

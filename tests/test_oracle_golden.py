@@ -181,6 +181,31 @@ def test_reproj_chain(golden):
     assert rel_err(zp.grad.numpy(), g["grad_zp"]) < TIGHT
 
 
+def test_reproj_chain_every_gradient_and_crops_per_sample(golden):
+    """The chain with every input asking for a gradient (the reference's autograd differentiates the depth, the
+    pose -- through linalg.inv and both uses of it --, xy and the pattern), zp_cView_to_zc on its own, and two
+    crops of one sample (B_sub = 2: broadcast pose, repeated inverse and pattern)."""
+    g = golden("g11_reproj_grads")
+    cx, cy = float(g["cx"]), float(g["cy"])
+    leaves = [t(g[k]).clone().requires_grad_(True) for k in ("zp", "pose", "xy", "IpGT")]
+    zc, _, Ic = orc.reproject_chain(leaves[0], leaves[1], leaves[2], leaves[3], cx, cy)
+    ((Ic * t(g["g_ic"])).sum() + (zc * t(g["g_zc"])).sum()).backward()
+    assert np.array_equal(zc.detach().numpy(), g["zc"]) and np.array_equal(Ic.detach().numpy(), g["Ic"])
+    for leaf, k in zip(leaves, ("grad_zp", "grad_pose", "grad_xy", "grad_IpGT")):
+        assert rel_err(leaf.grad.numpy(), g[k]) < TIGHT, k
+    leaves = [t(g[k]).clone().requires_grad_(True) for k in ("zp", "pose", "xy")]
+    (orc.zp_cView_to_zc(*leaves) * t(g["g_zc"])).sum().backward()
+    for leaf, k in zip(leaves, ("zc_only_grad_zp", "zc_only_grad_pose", "zc_only_grad_xy")):
+        assert rel_err(leaf.grad.numpy(), g[k]) < TIGHT, k
+    leaves = [t(g["zp"]).clone().requires_grad_(True), t(g["pose"][0:1]).clone().requires_grad_(True),
+              t(g["xy"]).clone().requires_grad_(True), t(g["IpGT"][0:1]).clone().requires_grad_(True)]
+    zc, _, Ic = orc.reproject_chain(*leaves, cx, cy)
+    ((Ic * t(g["g_ic"])).sum() + (zc * t(g["g_zc"])).sum()).backward()
+    assert np.array_equal(zc.detach().numpy(), g["sub_zc"]) and np.array_equal(Ic.detach().numpy(), g["sub_Ic"])
+    for leaf, k in zip(leaves, ("sub_grad_zp", "sub_grad_pose", "sub_grad_xy", "sub_grad_IpGT")):
+        assert rel_err(leaf.grad.numpy(), g[k]) < TIGHT, k
+
+
 def _g9_inputs(g):
     """Scene, pattern, PSFs and the three random draws of the g9 fixture, rebuilt from its seeds."""
     from fc3d import synth
