@@ -97,18 +97,48 @@ def layer_grid(n_layers: int, wvl: float, D: float, z0: float, z_min: float, z_m
 # tensor is unmodified and the consumer's own forward result is the image that was sampled;
 # anything else (gradients accumulated from several consumers -- a new tensor without the
 # attribute --, hooks that rewrite them, other images) takes the ordinary path.
+# The hand-over is watched: handover_stats counts offers, sums taken, sums refused (the gradient was modified
+# or belongs to another image) and sums lost -- offered for an image whose codePattern backward then ran
+# without seeing any offer, which is what a PyTorch that copies gradients between backward functions
+# would look like.  The first loss is reported with a warning; the result is right either way (the
+# ordinary two-launch backward runs), only a launch slower.
+handover_stats = {"offered": 0, "taken": 0, "refused": 0, "lost": 0}
+_pending_offers: dict = {}
+_warned_lost = False
+
+
 def _offer_grad_dot(grad: torch.Tensor, img: torch.Tensor, partials: torch.Tensor) -> None:
     grad._fc3d_dot = (grad._version, img.data_ptr(), img._version, tuple(img.shape), partials)
+    handover_stats["offered"] += 1
+    if len(_pending_offers) > 64:
+        _pending_offers.clear()
+    _pending_offers[img.data_ptr()] = img._version
 
 
 def _take_grad_dot(grad: torch.Tensor, out: torch.Tensor):
+    global _warned_lost
     hit = getattr(grad, "_fc3d_dot", None)
+    pending = _pending_offers.pop(out.data_ptr(), None)
     if hit is None:
+        if pending is not None and pending == out._version and grad.is_contiguous():
+            # a sum was offered for exactly this image, and the gradient that arrived does not carry it: either
+            # autograd summed gradients of several consumers (a new tensor: legitimate) or it no longer passes
+            # the producer's tensor object on
+            handover_stats["lost"] += 1
+            if not _warned_lost:
+                _warned_lost = True
+                import warnings
+                warnings.warn("fc3d: the sum(g * out) by-product offered by the sampler's backward did not reach "
+                              "codePattern's backward (several consumers of Ip_coded, a gradient hook, or a PyTorch "
+                              "that copies gradients between backward functions); using the two-launch backward",
+                              RuntimeWarning, stacklevel=3)
         return None
     version, img_ptr, img_version, img_shape, partials = hit
     if (grad._version != version or not grad.is_contiguous() or img_ptr != out.data_ptr()
             or img_version != out._version or img_shape != tuple(out.shape)):
+        handover_stats["refused"] += 1
         return None
+    handover_stats["taken"] += 1
     return partials
 
 

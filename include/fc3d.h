@@ -337,7 +337,10 @@ int fc3d_reproj_loss_bwd(void *stream, const float *g_losses, const float *sums,
  * that device current; the call never allocates or frees).  Limit: B * ceil(H*W/256) <= 65536
  * partial sums (e.g. 64 images of 512x512), otherwise FC3D_ESCRATCH and nothing is launched.
  * All calls on one GPU share that array: calls whose kernels may overlap on one GPU (different
- * streams, or several host threads) race on it and must be serialised by the caller.          */
+ * streams, or several host threads) race on it and must be serialised by the caller.
+ * The first call on each device looks the array's address up (hipGetSymbolAddress, which may load the
+ * code object): make that call OUTSIDE any stream capture -- one eager call per device at set-up; every
+ * later call, captured ones included, only enqueues the two kernels.                            */
 int fc3d_reproj_loss_fwd_static(void *stream, const float *zp_hat, const float *mask, const float *xy,
                                 const float *inv, const float *T, const float *img, const float *Ic,
                                 const float *zcGT, int B, int H, int W, int Hs, int Ws, float *sums,

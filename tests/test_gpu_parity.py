@@ -568,6 +568,7 @@ def test_backward_hands_sum_from_sampler_to_code_pattern(mods, K):
             return getattr(self._lib, name)
     lib = ops._lib
     ops._lib = Spy(lib)
+    stats0 = dict(ops.handover_stats)
     try:
         for mode in ("handed", "touched", "no_offer"):
             pat = dev(p0).requires_grad_(True)
@@ -586,6 +587,26 @@ def test_backward_hands_sum_from_sampler_to_code_pattern(mods, K):
         ops._lib = lib
     assert res["handed"][1] == {"dot": 1, "plain": 0}
     assert res["touched"][1] == {"dot": 0, "plain": 1} and res["no_offer"][1] == {"dot": 0, "plain": 1}
+    # the hand-over keeps count of itself: two offers (handed, touched), one taken, one refused, none lost
+    d = {k: ops.handover_stats[k] - stats0[k] for k in stats0}
+    assert d == {"offered": 2, "taken": 1, "refused": 1, "lost": 0}, d
+    # a second consumer of Ip_coded: autograd sums the two gradients into a new tensor, the offer cannot arrive;
+    # that is counted as lost and reported once (the same would show if PyTorch stopped passing the tensor on)
+    import warnings
+    pat = dev(p0).requires_grad_(True)
+    Ip = O.codePattern(pat, dev(sc["z_p"]), is_conv_psf=conv, n_layers=L)
+    Ic, _, _ = G._warp_p2c(Ip, coord_p, coord_c, dev(sc["pose_p2c"]), Kmat)
+    ops._warned_lost = False
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        ((Ic * up).sum() + 0.5 * Ip.sum()).backward()
+    assert ops.handover_stats["lost"] - stats0["lost"] == 1
+    assert any("did not reach" in str(w.message) for w in rec)
+    both = pat.grad.clone()
+    pat2 = dev(p0).requires_grad_(True)
+    Ip2 = O.codePattern(pat2, dev(sc["z_p"]), is_conv_psf=conv, n_layers=L)
+    (0.5 * Ip2.sum()).backward()
+    assert rel_err((both - pat2.grad).cpu().numpy(), res["handed"][0].cpu().numpy()) < 1e-4
     a, b = res["handed"][0].cpu().numpy(), res["touched"][0].cpu().numpy()
     assert float(np.abs(b).max()) > 0
     assert rel_err(a, b) < 1e-6 and rel_err_elem(a, b) < 1e-4

@@ -55,3 +55,35 @@ def test_static_scratch_entry_point_matches_workspace_entry_point():
     assert lib.fc3d_reproj_loss_fwd_static(None, one, one, one, one, one, one, one, one, 300, 512, 512, 512, 512,
                                            one, one) == -4
     assert b"static scratch" in lib.fc3d_status_string(-4)
+
+
+def test_static_scratch_entry_point_under_graph_capture():
+    """The use the entry point is for: captured into a HIP graph (after one eager call on the device, which does
+    the one-time symbol lookup outside any capture) and replayed on changing inputs, against the workspace
+    form called eagerly on the same inputs."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from fc3d import _native
+    lib, check = _native.load(), _native.check
+    B, H, W = 2, 64, 96
+    t = _inputs(B, H, W, 11)
+    ref0, got0 = _both(lib, check, t, B, H, W)                   # warm call: the device's array is looked up here
+    assert torch.equal(ref0, got0)
+    out = torch.full((8,), float("nan"), device="cuda")
+    p = lambda k: t[k].data_ptr()  # noqa: E731
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+        check(lib.fc3d_reproj_loss_fwd_static(torch.cuda.current_stream().cuda_stream, p("zp"), p("mask"), p("xy"),
+                                              p("inv"), p("T"), p("img"), p("Ic"), p("zc"), B, H, W, H, W,
+                                              out.data_ptr(), out.data_ptr() + 16), "fc3d_reproj_loss_fwd_static")
+    for seed in (12, 13, 11):
+        new = _inputs(B, H, W, seed)
+        for k in t:
+            t[k].copy_(new[k])                                    # the graph's input buffers, refilled in place
+        g.replay()
+        torch.cuda.synchronize()
+        ref, _ = _both(lib, check, t, B, H, W)
+        assert torch.equal(out.cpu(), ref), seed
+    assert torch.equal(out.cpu(), ref0)                           # seed 11 again: the first call's values
