@@ -535,6 +535,46 @@ def test_warp_pose_in_kernel_matches_separate_transforms(mods, golden, monkeypat
     assert int(mask.count_nonzero()) > 0            # mask_rezero = 0: the mask stays available
 
 
+def test_two_stream_warp_loop_needs_only_the_forward_wait(mods):
+    """An eager loop that issues the first half of warp_p2c on a side stream and orders ONLY
+    main.wait_stream(side) before the second half, as the docstring asks: the side stream runs ahead and would
+    splat the next scene into the pooled mask while the main stream's sampling kernel still reads and clears
+    it -- unless the buffer's next checkout waits for that kernel (the event stored with it).  Every iteration
+    must give what the one-call warp_p2c gives for its scene."""
+    G, ops, synth = mods["G"], mods["ops"], mods["synth"]
+    B, H, W = 8, 512, 512
+    rays = G.pixel_to_ray_array(W, H)
+    Kmat = dev(np.diag([1666.67, 1666.67, 1, 1]).astype(np.float32))
+    Kmat[0, 2], Kmat[1, 2] = W / 2, H / 2
+    scenes = []
+    for seed in (41, 42, 43):
+        sc = synth.make_scene(B, H, W, seed=seed, theta_deg=12.0, t_max=(0.1, 0.1, 0.03))   # strong occlusion: masks differ a lot
+        cp = G.points_in_camera_coords(dev(sc["z_p"]), rays).permute(0, 3, 1, 2)
+        cc = G.points_in_camera_coords(dev(sc["z_c"]), rays).permute(0, 3, 1, 2)
+        scenes.append((cp, cc, dev(sc["pose_p2c"])))
+    ip = dev(np.random.RandomState(9).uniform(0.2, 1, (B, H, W, 1)).astype(np.float32))
+    want = [tuple(t.clone() for t in G._warp_p2c(ip, cp, cc, pose, Kmat)) for cp, cc, pose in scenes]
+    assert not torch.equal(want[0][0], want[1][0])
+    torch.cuda.synchronize()
+    main, side = torch.cuda.current_stream(), torch.cuda.Stream()
+    side.wait_stream(main)                      # once, for the inputs made above
+    busy = torch.rand(4096, 4096, device="cuda")
+    got = []
+    for it in range(12):
+        cp, cc, pose = scenes[it % 3]
+        with torch.cuda.stream(side):
+            begun = G.warp_p2c_begin(cp, pose, Kmat)       # runs ahead of the main stream
+        busy = busy * 1.0001                               # the main stream is behind: work queued in front of the second half
+        main.wait_stream(side)
+        got.append(G.warp_p2c_finish(ip, cc, begun))
+    torch.cuda.synchronize()
+    for it, g3 in enumerate(got):
+        for a, b in zip(g3, want[it % 3]):
+            assert torch.equal(a, b), it
+    for m in ops._zero_masks.values():
+        assert int(m.count_nonzero()) == 0
+
+
 @pytest.mark.parametrize("K", [3, 5, 7, 9, 23, 0])
 def test_backward_hands_sum_from_sampler_to_code_pattern(mods, K):
     """codePattern -> warp_p2c backward: the sampler's image-gradient kernel hands sum(g * Ip_coded) to
