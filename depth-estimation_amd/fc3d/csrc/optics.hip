@@ -1146,9 +1146,22 @@ __global__ __launch_bounds__(NT) void code_pattern_flat_bwd_kernel(
 #ifndef FC3D_SWEEP_ROWS
 #define FC3D_SWEEP_ROWS 4
 #endif
+#ifndef FC3D_SWEEP_BWD_PSF_ROW_MAJOR
+#define FC3D_SWEEP_BWD_PSF_ROW_MAJOR 19   // smallest PSF size whose backward sweep runs PSF-row-major (0: none)
+#endif
+#ifndef FC3D_SWEEP_BWD_RM_WAVES
+#define FC3D_SWEEP_BWD_RM_WAVES 3
+#endif
 constexpr int kSweepCols = FC3D_SWEEP_COLS;       // output columns per wavefront (64 / kSweepCols row groups)
 constexpr int kSweepRows = FC3D_SWEEP_ROWS;       // output rows per lane
 constexpr int kSweepTileRows = (64 / kSweepCols) * kSweepRows;
+#ifndef FC3D_SWEEP_TWO_PASS
+#define FC3D_SWEEP_TWO_PASS 1
+#endif
+#ifndef FC3D_SWEEP_MANY_LAYERS
+#define FC3D_SWEEP_MANY_LAYERS 3
+#endif
+constexpr int kSweepManyLayers = FC3D_SWEEP_MANY_LAYERS;   // a tile whose layers span at least this many goes first
 #define FC3D_FOR_SWEEP_K(X) X(9) X(11) X(13) X(15) X(17) X(19) X(21) X(23) X(25) X(27) X(29) X(31) X(33)
 
 // Packed multiply-adds (v_pk_fma_f32: two per lane and instruction): a PSF row is consumed in pairs
@@ -1170,7 +1183,8 @@ struct Sweep {
     static constexpr int LW = NG == 1 ? LW0 : LW0 + ((4 - LW0 % 8) + 8) % 8;
     static constexpr int LWB = (LW0 + 3) & ~3;    // bytes per row of the staged layer tile
     // wavefronts per SIMD the backward kernel is compiled for: what its LDS tile lets a compute unit hold
-    static constexpr int BWD_WAVES = K <= 25 ? 4 : 3;
+    static constexpr bool PSF_ROW_MAJOR_BWD = FC3D_SWEEP_BWD_PSF_ROW_MAJOR != 0 && K >= FC3D_SWEEP_BWD_PSF_ROW_MAJOR;
+    static constexpr int BWD_WAVES = PSF_ROW_MAJOR_BWD ? FC3D_SWEEP_BWD_RM_WAVES : K <= 25 ? 4 : 3;
     static_assert(NG == 1 || R == 4, "the bank-spreading stride assumes four rows per lane");
 };
 
@@ -1199,6 +1213,24 @@ __device__ __forceinline__ void sweep_stage(const T* __restrict__ plane, unsigne
                 put(r, c, v[u], gy >= 0 && gy < H && gx >= 0 && gx < W);
             }
         }
+    }
+}
+
+// The same for a window that lies inside the image: lane c < LW0 loads column c of every row -- the
+// address is a scalar row base plus one fixed lane offset, the LDS address a constant offset from one
+// lane base, so a row costs a load and a store and no vector arithmetic (the clamped form above spends
+// about 25 vector instructions per cell on index splitting, clamping and bounds tests).
+template <int NR, int LW0, int LW, typename T>
+__device__ __forceinline__ void sweep_stage_inside(const T* __restrict__ first, unsigned row_stride, unsigned col_stride,
+                                                   int lane, float* __restrict__ tile) {
+    const bool on = lane < LW0;
+    const unsigned voff = (unsigned)min(lane, LW0 - 1) * col_stride;
+    T v[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) v[r] = ld_at(first + (size_t)r * row_stride, voff);
+    if (on) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) tile[r * LW + lane] = (float)v[r];
     }
 }
 
@@ -1274,29 +1306,149 @@ __device__ __forceinline__ void sweep_core(const float* mine, const float* __res
     }
 }
 
-template <int K, int R, int CW>
+// The same sweep with whole blocks of R PSF rows left out: `live` has bit r set when window row r (of
+// any row group) can hold a non-zero cell; a block of PSF rows d4 .. d4+R-1 reads rows d4 .. d4+2R-2.
+// Straight-line code per block behind a uniform branch; a block that follows a skipped one reloads
+// the R-1 rows the rotation would have left in registers.
+template <int K, int R, int LW, bool PK, bool FLIP>
+__device__ __forceinline__ void sweep_core_blocks(const float* mine, const float* __restrict__ wl,
+                                                  unsigned long long live, float (&acc)[R], f2 (&acc2)[R]) {
+    static_assert(R == 4, "the rotation is unrolled for four rows per lane");
+    float X[R][K];
+    float Wt[K];
+    auto load_row = [&](float (&x)[K], int r) {
+#pragma unroll
+        for (int e = 0; e < K; ++e) x[e] = mine[r * LW + e];
+    };
+    auto load_psf = [&](int dy) {
+        const float* wr = wl + (FLIP ? K - 1 - dy : dy) * K;
+#pragma unroll
+        for (int e = 0; e < K; ++e) Wt[e] = FLIP ? wr[K - 1 - e] : wr[e];
+    };
+    auto fma_pair = [&](int oa, const float (&xa)[K], const float (&xb)[K]) {
+        if (PK) {
+#pragma unroll
+            for (int e = 0; e + 1 < K; e += 2) {
+                acc2[oa] = __builtin_elementwise_fma(f2{Wt[e], Wt[e + 1]}, f2{xa[e], xa[e + 1]}, acc2[oa]);
+                acc2[oa + 1] = __builtin_elementwise_fma(f2{Wt[e], Wt[e + 1]}, f2{xb[e], xb[e + 1]}, acc2[oa + 1]);
+            }
+            acc2[oa].x = fmaf(Wt[K - 1], xa[K - 1], acc2[oa].x);
+            acc2[oa + 1].x = fmaf(Wt[K - 1], xb[K - 1], acc2[oa + 1].x);
+        } else {
+#pragma unroll
+            for (int e = 0; e < K; ++e) {
+                acc[oa] = fmaf(Wt[e], xa[e], acc[oa]);
+                acc[oa + 1] = fmaf(Wt[e], xb[e], acc[oa + 1]);
+            }
+        }
+    };
+    auto step = [&](int dy, float (&x0)[K], float (&x1)[K], float (&x2)[K], float (&x3)[K]) {
+        load_row(x3, dy + R - 1);
+        load_psf(dy);
+        fma_pair(0, x0, x1);
+        fma_pair(2, x2, x3);
+    };
+    bool have = false;                             // X[0..2] hold rows d4 .. d4+2
+#pragma unroll
+    for (int d4 = 0; d4 < K; d4 += R) {
+        constexpr unsigned long long kSpan = (1ull << (2 * R - 1)) - 1ull;
+        if (((live >> d4) & kSpan) == 0ull) {
+            have = false;
+            continue;
+        }
+        if (!have) {
+            load_row(X[0], d4);
+            load_row(X[1], d4 + 1);
+            load_row(X[2], d4 + 2);
+        }
+        have = true;
+        if (d4 + R <= K) {
+            step(d4, X[0], X[1], X[2], X[3]);
+            step(d4 + 1, X[1], X[2], X[3], X[0]);
+            step(d4 + 2, X[2], X[3], X[0], X[1]);
+            step(d4 + 3, X[3], X[0], X[1], X[2]);
+        } else {
+            step(d4, X[0], X[1], X[2], X[3]);
+            if (K % R == 3) {
+                step(d4 + 1, X[1], X[2], X[3], X[0]);
+                step(d4 + 2, X[2], X[3], X[0], X[1]);
+            }
+        }
+    }
+}
+
+template <int K, int R, int CW, bool INTC0 = false>
 __global__ __launch_bounds__(64) void code_pattern_fwd_sweep_kernel(
     const float* __restrict__ pat0, long sb, long sh, long sw, const float* __restrict__ z,
     const float* __restrict__ psf, int H, int W, fc3d_layer_grid lg, float* __restrict__ raw,
-    uint8_t* __restrict__ layer_u8, unsigned long long* __restrict__ tilekey) {
+    uint8_t* __restrict__ layer_u8, unsigned long long* __restrict__ tilekey, int two_pass) {
     using S = Sweep<K, R, CW>;
     constexpr bool PK = S::PK_FWD;
     constexpr int PAD = S::PAD, LW = S::LW, NRG = R + K - 1;       // NRG: input rows one row group reads
     extern __shared__ float smem[];               // [NR][LW]
     const int lane = threadIdx.x, col = lane % CW, grp = lane / CW;
-    const int b = blockIdx.z, x0 = blockIdx.x * CW, y0 = blockIdx.y * S::TR;
+    // Two passes over the tiles in one grid (the upper half of gridDim.z is the second pass): the first
+    // takes the tiles whose pixels span several depth layers, the second all others.  A tile costs one
+    // sweep per layer, up to ten times the average along depth edges; dispatched in image order the
+    // last of those decide when the launch ends, started first they run beside everything else.  A
+    // workgroup that meets a tile of the other pass leaves after the layer decision.
+    const int nb = two_pass ? gridDim.z / 2 : gridDim.z;
+    const int pass = blockIdx.z / nb, b = blockIdx.z - pass * nb;
+    const int x0 = blockIdx.x * CW, y0 = blockIdx.y * S::TR;
     const long img = (long)b * H * W;
     const int x = x0 + col, yg = y0 + grp * R;
 
-    sweep_stage<S::NR, S::LW0>(pat0 + (long)b * sb, (unsigned)sh, (unsigned)sw, H, W, x0 - PAD, y0 - PAD, lane,
-                               [&](int r, int c, float v, bool ok) { smem[r * LW + c] = ok ? v : 0.0f; });
+    auto stage = [&]() {
+        const bool inside = x0 - PAD >= 0 && x0 - PAD + S::LW0 <= W && y0 - PAD >= 0 && y0 - PAD + S::NR <= H;   // (uniform)
+        if (inside)
+            sweep_stage_inside<S::NR, S::LW0, LW>(pat0 + (long)b * sb + (long)(y0 - PAD) * sh + (long)(x0 - PAD) * sw,
+                                                  (unsigned)sh, (unsigned)sw, lane, smem);
+        else
+            sweep_stage<S::NR, S::LW0>(pat0 + (long)b * sb, (unsigned)sh, (unsigned)sw, H, W, x0 - PAD, y0 - PAD, lane,
+                                       [&](int r, int c, float v, bool ok) { smem[r * LW + c] = ok ? v : 0.0f; });
+    };
     int lay[R];
+    // the layers of the lane's pixels (reciprocal shortcut; the exact chain for the whole tile when any pixel
+    // is flagged); returns whether the tile belongs to the first pass
+    auto decide = [&]() -> bool {
+        const LayerFast lfast = layer_fast_setup(lg);
+        float zv[R];
+        bool amb = false;
 #pragma unroll
-    for (int o = 0; o < R; ++o) {
-        const int y = yg + o;
-        const bool inb = y < H && x < W;
-        const float zv = ld_at(z + img, (unsigned)(min(y, H - 1) * W + min(x, W - 1)));
-        lay[o] = inb ? layer_of(zv, lg) : -1;
+        for (int o = 0; o < R; ++o) {
+            const int y = yg + o;
+            zv[o] = ld_at(z + img, (unsigned)(min(y, H - 1) * W + min(x, W - 1)));
+        }
+#pragma unroll
+        for (int o = 0; o < R; ++o) {
+            bool a;
+            lay[o] = layer_fast<INTC0>(zv[o], lg, lfast, a);
+            amb |= a;
+        }
+        if (__ballot(amb) != 0ull) {
+#pragma unroll
+            for (int o = 0; o < R; ++o) lay[o] = layer_of(zv[o], lg);
+        }
+        int lo = 0x7fffffff, hi = -1;
+#pragma unroll
+        for (int o = 0; o < R; ++o) {
+            lay[o] = (yg + o < H && x < W) ? lay[o] : -1;
+            if (lay[o] >= 0) {
+                lo = min(lo, lay[o]);
+                hi = max(hi, lay[o]);
+            }
+        }
+        return wave_max(hi) - wave_min(lo) >= kSweepManyLayers - 1;
+    };
+    if (!two_pass) {
+        stage();
+        decide();
+    } else if (pass == 0) {
+        if (!decide()) return;
+        stage();
+    } else {
+        stage();
+        if (decide()) return;
     }
     __syncthreads();
 
@@ -1390,7 +1542,7 @@ __global__ __launch_bounds__(64) void code_pattern_fwd_sweep_kernel(
 template <int K, int R, int CW>
 static size_t sweep_bwd_lds() {
     using S = Sweep<K, R, CW>;
-    return (size_t)((S::NR * S::LW + 63) / 64) * 64 * 4 + (size_t)S::NR * S::LWB;     // tile in whole 64-cell slices
+    return (size_t)((S::NR * S::LW + 63) / 64) * 64 * 5;     // tile and layer tile in whole 64-cell slices
 }
 
 // The staged cells (gradient / (max + eps) and layer id) stay in registers for the whole kernel, CPL
@@ -1408,20 +1560,46 @@ void code_pattern_bwd_sweep_kernel(
     const float* __restrict__ g, const float* __restrict__ out, const uint8_t* __restrict__ layer_u8,
     const float* __restrict__ max_in, const float* __restrict__ psf, int H, int W, int L,
     float* __restrict__ partial, float* __restrict__ g_pat0, const int* __restrict__ argmax_in,
-    const float* __restrict__ dot_partial, int ndot) {
+    const float* __restrict__ dot_partial, int ndot, int two_pass) {
     using S = Sweep<K, R, CW>;
-    constexpr int PAD = S::PAD, LW = S::LW, LW0 = S::LW0, LWB = S::LWB, NR = S::NR, NG = S::NG, NRG = R + K - 1;
+    constexpr int PAD = S::PAD, LW = S::LW, LW0 = S::LW0, LWB = S::LW, NR = S::NR, NG = S::NG, NRG = R + K - 1;
     constexpr bool PK = S::PK_BWD;
     constexpr int HB = K - 1 - PAD;               // halo rows / columns before the tile
     constexpr int N = NR * LW, CPL = (N + 63) / 64;               // cells of the LDS tile (padding included), per lane
     static_assert(NR <= 64, "one lane per staged row");
     extern __shared__ float smem[];
     float* mt = smem;                                              // [NR][LW] the tile masked to the current layer
-    uint8_t* lt = reinterpret_cast<uint8_t*>(mt + CPL * 64);       // [NR][LWB] layer of every staged pixel (255: none)
+    uint8_t* lt = reinterpret_cast<uint8_t*>(mt + CPL * 64);       // [NR][LW] layer of every staged pixel (255: none), cell for cell like mt
     const int lane = threadIdx.x, col = lane % CW, grp = lane / CW;
-    const int b = blockIdx.z, x0 = blockIdx.x * CW, y0 = blockIdx.y * S::TR;
+    // two passes over the tiles in one grid, the tiles with many layers first (see the forward kernel)
+    const int nb = two_pass ? gridDim.z / 2 : gridDim.z;
+    const int pass = blockIdx.z / nb, b = blockIdx.z - pass * nb;
+    const int x0 = blockIdx.x * CW, y0 = blockIdx.y * S::TR;
     const long img = (long)b * H * W;
     const int x = x0 + col, yg = y0 + grp * R;
+
+    // Which pass the tile belongs to, from a TR x CW lattice of samples over the staged window (the same
+    // samples in both passes, or a tile could be taken twice or never): loads here, verdict below.
+    uint8_t smp[R];
+    if (two_pass) {
+#pragma unroll
+        for (int o = 0; o < R; ++o) {
+            const int r = ((grp * R + o) * (NR - 1)) / (S::TR - 1), c = (col * (LW0 - 1)) / (CW - 1);
+            smp[o] = ld_at(layer_u8 + img, (unsigned)min(max(y0 - HB + r, 0), H - 1) * (unsigned)W +
+                                               (unsigned)min(max(x0 - HB + c, 0), W - 1));
+        }
+    }
+    auto many_layers = [&]() -> bool {
+        int lo = 255, hi = -1;
+#pragma unroll
+        for (int o = 0; o < R; ++o)
+            if (smp[o] != 255) {
+                lo = min(lo, (int)smp[o]);
+                hi = max(hi, (int)smp[o]);
+            }
+        return wave_max(hi) - wave_min(lo) >= kSweepManyLayers - 1;
+    };
+    if (two_pass && pass == 0 && !many_layers()) return;
     const float rden = 1.0f / (max_in[b] + 1e-10f);
 
     // Stage.  Lane `lane` keeps tile cells lane, lane + 64, ... (so a sweep's stores need no address
@@ -1431,6 +1609,33 @@ void code_pattern_bwd_sweep_kernel(
 #pragma unroll
     for (int v = 0; v < (CPL + 3) / 4; ++v) lv[v] = 0u;
     constexpr int SB = 16;                                         // cells of a lane loaded per batch
+    // A window that lies inside the image with its padding columns and one more row needs no clamping
+    // and no bounds tests: cell i is element base + i + (i / LW) * (W - LW) of the plane.
+    const bool inside = x0 - HB >= 0 && x0 - HB + LW <= W && y0 - HB >= 0 && y0 - HB + NR + 1 <= H;   // (uniform)
+    if (inside) {
+        const unsigned base = (unsigned)(y0 - HB) * (unsigned)W + (unsigned)(x0 - HB);
+#pragma unroll
+        for (int u0 = 0; u0 < CPL; u0 += SB) {
+            uint8_t lb[SB];
+#pragma unroll
+            for (int u = u0; u < min(u0 + SB, CPL); ++u) {
+                const unsigned i = (unsigned)(u * 64 + lane);
+                const unsigned q = base + i + (i / (unsigned)LW) * (unsigned)(W - LW);
+                gv[u] = ld_at(g + img, q);
+                lb[u - u0] = ld_at(layer_u8 + img, q);
+            }
+#pragma unroll
+            for (int u = u0; u < min(u0 + SB, CPL); ++u) {
+                const unsigned i = (unsigned)(u * 64 + lane);
+                const bool cell = i % (unsigned)LW < (unsigned)LW0 && (u * 64 + 63 < N || i < (unsigned)N);
+                const uint32_t l = cell ? (uint32_t)lb[u - u0] : 255u;
+                gv[u] = cell ? gv[u] * rden : 0.0f;
+                lv[u / 4] |= l << (8 * (u % 4));
+                lt[u * 64 + lane] = (uint8_t)l;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else
 #pragma unroll
     for (int u0 = 0; u0 < CPL; u0 += SB) {
         uint8_t lb[SB];
@@ -1456,6 +1661,7 @@ void code_pattern_bwd_sweep_kernel(
         }
         __builtin_amdgcn_sched_barrier(0);                         // keep the batches apart: registers, not latency, are short here
     }
+    if (two_pass && pass == 1 && many_layers()) return;
     if (DOT) {
         // the maximum's pixel, if this tile stages it (the same test in every lane): cell (pr, pc) of the tile
         const int am = argmax_in[b];
@@ -1524,6 +1730,17 @@ void code_pattern_bwd_sweep_kernel(
             // Row r of a group's window, column col+e is source (yg-HB+r, x-HB+e); it reaches output row o
             // through PSF row K-1-(r-o) and PSF column K-1-e.  Rows R-1 .. K-1 feed all R output rows
             // (straight-line code, see the forward kernel); the first and last R-1 rows take the branchy form.
+#if FC3D_SWEEP_BWD_PSF_ROW_MAJOR
+            if constexpr (K >= FC3D_SWEEP_BWD_PSF_ROW_MAJOR) {
+                // window rows (of any row group) that hold a pixel of this layer, as one range
+                unsigned long long any = 0ull;
+#pragma unroll
+                for (int gq = 0; gq < NG; ++gq) any |= rows >> (gq * R);
+                any &= (1ull << NRG) - 1ull;
+                sweep_core_blocks<K, R, LW, PK, true>(mine, psf + (long)l * K * K, any, acc, acc2);
+                continue;
+            }
+#endif
             auto row_step = [&](int r, auto full) {
                 constexpr bool FULL = decltype(full)::value;
                 if (((rows >> r) & kGroupRows) == 0ull) return;   // no group has a pixel of this layer in its row r
@@ -1676,11 +1893,14 @@ extern "C" int fc3d_code_pattern_fwd(void* stream, const float* pat0, int64_t pa
     if (Kw == KV) {                                                                                              \
         using SW = Sweep<KV, kSweepRows, kSweepCols>;                                                            \
         const size_t slds = (size_t)SW::NR * SW::LW * sizeof(float);                                             \
-        const dim3 gsw(cdiv(W, kSweepCols), cdiv(H, kSweepTileRows), B);                                         \
+        const int two_pass = FC3D_SWEEP_TWO_PASS && 2 * B <= 65535;                                              \
+        const dim3 gsw(cdiv(W, kSweepCols), cdiv(H, kSweepTileRows), two_pass ? 2 * B : B);                      \
         *keys_per_image = (int)(gsw.x * gsw.y);                                                                  \
-        FC3D_LAUNCH("code_pattern_fwd", (code_pattern_fwd_sweep_kernel<KV, kSweepRows, kSweepCols>), gsw,        \
+        auto kern = layer_grid_centre_is_integer(grid) ? code_pattern_fwd_sweep_kernel<KV, kSweepRows, kSweepCols, true>  \
+                                                       : code_pattern_fwd_sweep_kernel<KV, kSweepRows, kSweepCols, false>; \
+        FC3D_LAUNCH("code_pattern_fwd", kern, gsw,                                                               \
                     dim3(64), slds, s, pat0, (long)pat_sb, (long)pat_sh, (long)pat_sw, z, psf, H, W, grid,       \
-                    raw_out, layer_u8, (unsigned long long*)tilekey_u64);                                        \
+                    raw_out, layer_u8, (unsigned long long*)tilekey_u64, two_pass);                              \
         return FC3D_OK;                                                                                          \
     }
         FC3D_FOR_SWEEP_K(FC3D_FWD_SWEEP_CASE)
@@ -1808,10 +2028,11 @@ extern "C" int fc3d_code_pattern_bwd(void* stream, const float* g_out, const flo
 #define FC3D_BWD_SWEEP_CASE(KV)                                                                                  \
     if (Kw == KV) {                                                                                              \
         const size_t slds = sweep_bwd_lds<KV, kSweepRows, kSweepCols>();                                         \
-        const dim3 gsw(cdiv(W, kSweepCols), cdiv(H, kSweepTileRows), B);                                         \
+        const int two_pass = FC3D_SWEEP_TWO_PASS && 2 * B <= 65535;                                              \
+        const dim3 gsw(cdiv(W, kSweepCols), cdiv(H, kSweepTileRows), two_pass ? 2 * B : B);                      \
         FC3D_LAUNCH("code_pattern_bwd", (code_pattern_bwd_sweep_kernel<KV, kSweepRows, kSweepCols>), gsw,        \
                     dim3(64), slds, s, g_out, out, layer_u8, max_in, psf, H, W, L, partial, g_pat0,              \
-                    (const int*)nullptr, (const float*)nullptr, 0);                                              \
+                    (const int*)nullptr, (const float*)nullptr, 0, two_pass);                                    \
         FC3D_LAUNCH("code_pattern_bwd_max", code_pattern_bwd_max_kernel, dim3(B), dim3(NT), 0, s,                \
                     (const float*)partial, (int)(gsw.x * gsw.y), max_in, argmax_i32, layer_u8, psf, H, W, KV,    \
                     g_pat0);                                                                                     \
@@ -1869,10 +2090,11 @@ extern "C" int fc3d_code_pattern_bwd_dot(void* stream, const float* g_out, const
 #define FC3D_BWD_DOT_SWEEP_CASE(KV)                                                                              \
     if (Kw == KV) {                                                                                              \
         const size_t slds = sweep_bwd_lds<KV, kSweepRows, kSweepCols>();                                         \
-        const dim3 gsw(cdiv(W, kSweepCols), cdiv(H, kSweepTileRows), B);                                         \
+        const int two_pass = FC3D_SWEEP_TWO_PASS && 2 * B <= 65535;                                              \
+        const dim3 gsw(cdiv(W, kSweepCols), cdiv(H, kSweepTileRows), two_pass ? 2 * B : B);                      \
         FC3D_LAUNCH("code_pattern_bwd", (code_pattern_bwd_sweep_kernel<KV, kSweepRows, kSweepCols, true>), gsw,  \
                     dim3(64), slds, s, g_out, (const float*)nullptr, layer_u8, max_in, psf, H, W, L,             \
-                    (float*)nullptr, g_pat0, (const int*)argmax_i32, dot_partial, n_partial);                    \
+                    (float*)nullptr, g_pat0, (const int*)argmax_i32, dot_partial, n_partial, two_pass);          \
         return FC3D_OK;                                                                                          \
     }
     FC3D_FOR_SWEEP_K(FC3D_BWD_DOT_SWEEP_CASE)

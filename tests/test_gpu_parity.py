@@ -166,6 +166,44 @@ def test_code_pattern_vs_oracle_ragged(mods):
         assert np.array_equal(got, li[..., 0].numpy())
 
 
+def test_code_pattern_sweep_tiles_of_both_passes(mods):
+    """The large-PSF kernels run the tiles that span many depth layers first and the rest in a second
+    pass of the same grid, and stage tiles whose window lies inside the image without clamping: a scene
+    with flat parts, a slow ramp, a steep ramp and a step, large enough to hold tiles of every kind
+    (border and inner, one layer and many), against the oracle -- layers, image and gradient."""
+    O, synth, orc = mods["O"], mods["synth"], mods["orc"]
+    rs = np.random.RandomState(77)
+    B, H, W, L = 2, 112, 144, 41
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    z0 = np.where(xx < 40, 0.80, np.where(xx < 72, 0.70 + 0.25 * (xx - 40) / 32.0, 0.74 + 0.0004 * yy))
+    z0 = np.where((yy > 60) & (xx > 100), 0.93, z0)
+    z1 = 0.7 + 0.25 * ((xx * 7 + yy * 3) % 97) / 97.0 * (yy > 48) + 0.1 * (yy <= 48)
+    z = np.stack([z0, z1])[..., None].astype(np.float32)
+    p0 = rs.uniform(0, 1, (B, H, W, 1)).astype(np.float32)
+    gg = rs.uniform(-1, 1, (B, H, W, 1)).astype(np.float32)
+    li = orc.layer_index(t(z), L)[..., 0].numpy()
+    per_tile = [len(np.unique(li[0, y:y + 16, x:x + 16])) for y in range(0, H, 16) for x in range(0, W, 16)]
+    assert min(per_tile) == 1 and max(per_tile) >= 6          # the scene has tiles of both passes
+    for K, kind in ((9, "rand"), (23, "disc"), (19, "rand")):
+        psfs = synth.make_psfs(L, K, kind)
+        O.PSFs_np = psfs
+        a = dev(p0).requires_grad_(True)
+        out = O.codePattern(a, dev(z), n_layers=L)
+        out.backward(dev(gg))
+        pc = t(np.repeat(p0, L, axis=-1)).requires_grad_(True)
+        ref = orc.codePattern(pc, t(z), psfs, True)
+        ref.backward(t(gg))
+        assert rel_err(out.detach().cpu().numpy(), ref.detach().numpy()) < TOL, K
+        assert rel_err(a.grad.cpu().numpy(), pc.grad[..., 0:1].numpy()) < TOL, K
+        a2 = dev(p0).requires_grad_(True)
+        out2, layer, _, _ = mods["ops"].CodePatternFn.apply(a2, dev(z), O._device_psfs(a2.device), O._layer_grid(L), True)
+        got = layer.cpu().numpy().astype(np.int64)
+        got[got == 255] = -1
+        assert np.array_equal(got, li), K
+        (out2 * dev(gg)).sum().backward()
+        assert rel_err(a2.grad.cpu().numpy(), pc.grad[..., 0:1].numpy()) < TOL, K
+
+
 def test_code_pattern_without_blur_vs_oracle(mods):
     """is_conv_psf=False (the mode the reference's training loop runs): ragged and 4-divisible sizes,
     images larger than one wavefront's run, out-of-range depths, a strided channel-0 view."""
