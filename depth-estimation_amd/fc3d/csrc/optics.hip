@@ -1538,6 +1538,17 @@ __global__ __launch_bounds__(64) void code_pattern_fwd_sweep_kernel(
     if (lane == 0) tilekey[((long)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = key;
 }
 
+// Whether a launch runs the tiles with many layers first.  The second look at every tile costs a wavefront's
+// start and one memory latency per tile; what it buys is the tail of the launch, which is a smaller share
+// the more rounds of tiles the chip works through (256 compute units x 16 wavefronts hold 4,096 tiles at a
+// time) and the cheaper a sweep is.  Measured on 23x23 ... 9x9 PSFs: 4 x 1024 x 1024 (16 k tiles, 41 layers)
+// gains 10-25 % from 13x13 on and nothing at 9x9; 32 x 512 x 512 (33 k tiles, 21 layers) loses 10-20 % at
+// every size.
+static int sweep_two_pass(int K, int B, int H, int W) {
+    const long tiles = (long)cdiv(W, kSweepCols) * cdiv(H, kSweepTileRows) * B;
+    return FC3D_SWEEP_TWO_PASS && 2 * B <= 65535 && K >= 11 && tiles <= 6L * 4096;
+}
+
 // LDS bytes of the backward sweep kernel: the tile masked to the current layer and the layer tile.
 template <int K, int R, int CW>
 static size_t sweep_bwd_lds() {
@@ -1893,7 +1904,7 @@ extern "C" int fc3d_code_pattern_fwd(void* stream, const float* pat0, int64_t pa
     if (Kw == KV) {                                                                                              \
         using SW = Sweep<KV, kSweepRows, kSweepCols>;                                                            \
         const size_t slds = (size_t)SW::NR * SW::LW * sizeof(float);                                             \
-        const int two_pass = FC3D_SWEEP_TWO_PASS && 2 * B <= 65535;                                              \
+        const int two_pass = sweep_two_pass(KV, B, H, W);                                                        \
         const dim3 gsw(cdiv(W, kSweepCols), cdiv(H, kSweepTileRows), two_pass ? 2 * B : B);                      \
         *keys_per_image = (int)(gsw.x * gsw.y);                                                                  \
         auto kern = layer_grid_centre_is_integer(grid) ? code_pattern_fwd_sweep_kernel<KV, kSweepRows, kSweepCols, true>  \
@@ -2028,7 +2039,7 @@ extern "C" int fc3d_code_pattern_bwd(void* stream, const float* g_out, const flo
 #define FC3D_BWD_SWEEP_CASE(KV)                                                                                  \
     if (Kw == KV) {                                                                                              \
         const size_t slds = sweep_bwd_lds<KV, kSweepRows, kSweepCols>();                                         \
-        const int two_pass = FC3D_SWEEP_TWO_PASS && 2 * B <= 65535;                                              \
+        const int two_pass = sweep_two_pass(KV, B, H, W);                                                        \
         const dim3 gsw(cdiv(W, kSweepCols), cdiv(H, kSweepTileRows), two_pass ? 2 * B : B);                      \
         FC3D_LAUNCH("code_pattern_bwd", (code_pattern_bwd_sweep_kernel<KV, kSweepRows, kSweepCols>), gsw,        \
                     dim3(64), slds, s, g_out, out, layer_u8, max_in, psf, H, W, L, partial, g_pat0,              \
@@ -2090,7 +2101,7 @@ extern "C" int fc3d_code_pattern_bwd_dot(void* stream, const float* g_out, const
 #define FC3D_BWD_DOT_SWEEP_CASE(KV)                                                                              \
     if (Kw == KV) {                                                                                              \
         const size_t slds = sweep_bwd_lds<KV, kSweepRows, kSweepCols>();                                         \
-        const int two_pass = FC3D_SWEEP_TWO_PASS && 2 * B <= 65535;                                              \
+        const int two_pass = sweep_two_pass(KV, B, H, W);                                                        \
         const dim3 gsw(cdiv(W, kSweepCols), cdiv(H, kSweepTileRows), two_pass ? 2 * B : B);                      \
         FC3D_LAUNCH("code_pattern_bwd", (code_pattern_bwd_sweep_kernel<KV, kSweepRows, kSweepCols, true>), gsw,  \
                     dim3(64), slds, s, g_out, (const float*)nullptr, layer_u8, max_in, psf, H, W, L,             \
