@@ -1546,6 +1546,7 @@ __global__ __launch_bounds__(64) void code_pattern_fwd_sweep_kernel(
 // every size.
 static int sweep_two_pass(int K, int B, int H, int W) {
     const long tiles = (long)cdiv(W, kSweepCols) * cdiv(H, kSweepTileRows) * B;
+    if (FC3D_SWEEP_TWO_PASS == 2) return 2 * B <= 65535;      // (experiments: always)
     return FC3D_SWEEP_TWO_PASS && 2 * B <= 65535 && K >= 11 && tiles <= 6L * 4096;
 }
 
