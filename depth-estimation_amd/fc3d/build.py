@@ -64,14 +64,29 @@ def needs_build() -> bool:
 
 
 def build(force: bool = False, verbose: bool = True, extra_flags=(), out: str = LIB) -> str:
-    """extra_flags / out: experiment builds (e.g. -D switches) into another file."""
+    """extra_flags / out: experiment builds (e.g. -D switches) into another file.
+    The sources are compiled side by side (one hipcc per file), then linked."""
     if not force and out == LIB and not needs_build():
         return LIB
-    cmd = [_hipcc(), *FLAGS, *extra_flags, "-I", os.path.join(ROOT, "include"), "-I", CSRC,
-           *[os.path.join(CSRC, s) for s in SOURCES], "-o", out]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    cflags = [f for f in FLAGS if f != "-shared"]
+    with tempfile.TemporaryDirectory(prefix="fc3d_build_") as tmp:
+        def compile_one(src):
+            obj = os.path.join(tmp, src + ".o")
+            cmd = [_hipcc(), *cflags, *extra_flags, "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c",
+                   os.path.join(CSRC, src), "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            return obj
+        with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1, 8)) as pool:
+            objs = list(pool.map(compile_one, SOURCES))
+        link = [_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", "-fno-gpu-rdc", *objs, "-o", out + ".tmp"]
+        if verbose:
+            print(" ".join(link), flush=True)
+        subprocess.check_call(link)
+    os.replace(out + ".tmp", out)
     if out == LIB:
         with open(STAMP, "w") as f:
             f.write(source_hash(extra_flags) + "\n")
