@@ -86,6 +86,11 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--n1-value", type=float, default=None,
                     help="captures/s of a previous --gpus 1 run: the line then carries scaling_efficiency_vs_n1")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="run all N ranks on GPU 0, with gloo for the barrier and the timing reductions (RCCL refuses two "
+                         "ranks on one device): the whole N-rank path of this benchmark -- child ranks, rendezvous, real "
+                         "kernels, per-rank rates, one line from rank 0 -- on a box with a single GPU.  The value is not "
+                         "a scaling measurement (the ranks share the GPU) and the line says so")
     ap.add_argument("--launch-selftest", action="store_true",
                     help="exercise the launch / rendezvous / max-over-ranks / reporting path with gloo ranks and a host "
                          "stand-in for the step: touches no GPU (for machines without one and for CPU tests)")
@@ -272,12 +277,19 @@ def main():
         return selftest(args, world, rank)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if args.rehearse_on_one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None
+    coll_device = device                 # where the tensors of the timing collectives live
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+            coll_device = torch.device("cpu")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     from fc3d import ops as fc3d_ops, profiler
     fc3d_ops.set_image_gradient_mode(args.bwd)
@@ -344,10 +356,10 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=coll_device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    per_rank = rank_rates(cfg["B"] * args.steps / own, world, dist, device)
+    per_rank = rank_rates(cfg["B"] * args.steps / own, world, dist, coll_device)
 
     # the same K steps issued the two other ways, after the timed region (reported beside the headline): one
     # graph launch per step -- what a caller that runs one step per iteration sees -- and launch by launch
@@ -430,6 +442,8 @@ def main():
                             "alg_GBps": round(v["alg_bytes_per_launch"] / (v["avg_us"] * 1e-6) / 1e9, 1)}
                         for k, v in kern.items()},
         }
+        if args.rehearse_on_one_gpu:
+            out["rehearsal"] = f"all {world} ranks on GPU 0, gloo for the timing collectives: exercises the N-rank path, measures no scaling"
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(wl, args.cpu_seconds)
             out["cpu_baseline"] = cb
