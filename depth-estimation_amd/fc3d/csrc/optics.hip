@@ -1591,7 +1591,7 @@ void code_pattern_bwd_sweep_kernel(
     const int x = x0 + col, yg = y0 + grp * R;
 
     // Which pass the tile belongs to, from a TR x CW lattice of samples over the staged window (the same
-    // samples in both passes, or a tile could be taken twice or never): loads here, verdict below.
+    // samples in both passes, or a tile could be taken twice or never): loads here, the decision below.
     uint8_t smp[R];
     if (two_pass) {
 #pragma unroll
