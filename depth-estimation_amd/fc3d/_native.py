@@ -19,6 +19,8 @@ class LayerGrid(ctypes.Structure):
                 ("n_layers", c_int32)]
 
 
+ABI_VERSION = 210  # FC3D_VERSION of include/fc3d.h this binding was written against (a stale library is refused)
+
 P = c_void_p      # device pointers travel as integers
 I64 = c_int64
 
@@ -107,8 +109,8 @@ def load() -> ctypes.CDLL:
             raise ImportError(f"{LIB_PATH} does not export {name}; rebuild it") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.fc3d_version() != 200:
-        raise ImportError(f"{LIB_PATH} reports version {lib.fc3d_version()}, expected 200; rebuild it")
+    if lib.fc3d_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} reports version {lib.fc3d_version()}, expected {ABI_VERSION}; rebuild it")
     _lib = lib
     return lib
 

@@ -36,7 +36,7 @@ extern "C" {
 #define FC3D_EALIGN (-3)     /* pointer not aligned to its element type */
 #define FC3D_ESCRATCH (-4)   /* problem larger than the library's static scratch buffer */
 
-#define FC3D_VERSION 200
+#define FC3D_VERSION 210
 
 int fc3d_version(void);
 const char *fc3d_status_string(int status);
