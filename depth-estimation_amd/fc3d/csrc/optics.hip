@@ -1621,9 +1621,11 @@ void code_pattern_bwd_sweep_kernel(
 #pragma unroll
     for (int v = 0; v < (CPL + 3) / 4; ++v) lv[v] = 0u;
     constexpr int SB = 16;                                         // cells of a lane loaded per batch
-    // A window that lies inside the image with its padding columns and one more row needs no clamping
-    // and no bounds tests: cell i is element base + i + (i / LW) * (W - LW) of the plane.
-    const bool inside = x0 - HB >= 0 && x0 - HB + LW <= W && y0 - HB >= 0 && y0 - HB + NR + 1 <= H;   // (uniform)
+    // A window that lies inside the image with its padding columns and the rows that the cells past the
+    // tile (the last lanes' share of the final 64-cell slice) fall into needs no clamping and no bounds
+    // tests: cell i is element base + i + (i / LW) * (W - LW) of the plane.
+    constexpr int RLAST = (CPL * 64 - 1) / LW;                     // last window row any lane's cell index reaches
+    const bool inside = x0 - HB >= 0 && x0 - HB + LW <= W && y0 - HB >= 0 && y0 - HB + RLAST + 1 <= H;   // (uniform)
     if (inside) {
         const unsigned base = (unsigned)(y0 - HB) * (unsigned)W + (unsigned)(x0 - HB);
 #pragma unroll
