@@ -293,11 +293,17 @@ def main():
 
     from fc3d import ops as fc3d_ops, profiler
     fc3d_ops.set_image_gradient_mode(args.bwd)
+    # The headline reads the scene points as the tensors they are handed over as (16 B per pixel and warp: the
+    # 100 B/px the roofline is quoted on).  The library's default for points that come from
+    # points_in_camera_coords -- read the 4-byte depth behind them and form the point in the kernel -- is
+    # measured after the timed region and reported beside it.
+    fc3d_ops.set_points_from_depth(False)
     wl, tens = build_inputs(args, rank, device)
     cfg = wl["cfg"]
     B, H, W = cfg["B"], cfg["H"], cfg["W"]
     step = make_step(tens)          # eager step: used for the per-kernel event pass in either mode
     launch = "eager"
+    gd, gd_form = None, None
 
     def run_steps(k):
         for _ in range(k):
@@ -318,6 +324,18 @@ def main():
             gf = GraphedImageFormation(tens["pat"], tens["z_p"], tens["coord_p"], tens["coord_c"], tens["pose"],
                                        tens["g"], tens["L"], unroll=unroll, overlap=args.overlap)
             run_steps, launch = gf.replay_steps, f"hip_graph x{unroll}" + (", projection beside codePattern" if args.overlap else "")
+            if rank == 0:
+                # a second graph of the same step with the depth-plane form of the coordinate reads (captured here,
+                # before any eager step has left autograd nodes of the default stream behind; timed after the headline)
+                fc3d_ops.set_points_from_depth(True)
+                try:
+                    gd = GraphedImageFormation(tens["pat"], tens["z_p"], tens["coord_p"], tens["coord_c"], tens["pose"],
+                                               tens["g"], tens["L"], unroll=unroll, overlap=args.overlap)
+                    gd_form = fc3d_ops.WarpP2CPoseFn.last_form
+                except Exception as e:
+                    gd, gd_form = None, f"{type(e).__name__}: {e}"
+                finally:
+                    fc3d_ops.set_points_from_depth(False)
         except Exception as e:   # capture refused (e.g. by another library's activity): measure eager instead
             print(f"[bench] graph capture failed ({type(e).__name__}: {e}); using eager launches", file=sys.stderr)
             torch.cuda.synchronize()
@@ -395,6 +413,25 @@ def main():
         if not replay_ok:
             print("[bench] WARNING: graph replay and eager results differ", file=sys.stderr)
 
+    # the same step with the depth-plane form of the coordinate reads (the library's default), through the same
+    # kind of graph; its results must equal the stored-points form bit for bit
+    from_depth = None
+    if rank == 0 and launch.startswith("hip_graph"):
+        if gd is None:
+            from_depth = {"error": gd_form}
+        else:
+            Ic_d, gr_d = (x.clone() for x in gd.replay_steps(unroll))
+            Ic_p = step()                      # eager, stored-points form (the switch is off)
+            same = bool(torch.equal(Ic_d, Ic_p)) and bool(torch.equal(gr_d, tens["pat"].grad))
+            gd.replay_steps(max(unroll, (args.settle // unroll) * unroll))
+            ms_d = timed(gd.replay_steps, args.steps)
+            from_depth = {"form_used": gd_form, "ms_per_step": ms_d, "captures_per_s": B * 1e3 / ms_d,
+                          "alg_bytes_per_capture": 76 * H * W,
+                          "path_frac_per_gpu_on_76_B_per_px": (B * 1e3 / ms_d) * 76 * H * W / HBM_PEAK,
+                          "equals_stored_points_form": same,
+                          "note": "coord_p / coord_c carry the note of points_in_camera_coords: the two warp kernels read "
+                                  "z (4 B/px) and form the point as stored instead of reading it (16 B/px); not the headline"}
+
     if rank == 0:
         px = B * H * W
         kern = {k: dict(launches=n, avg_us=1e3 * ms / n, alg_bytes_per_launch=ALG_BYTES.get(k, 0) * px)
@@ -418,6 +455,7 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "ms_per_step_graph_x1": ms_graph_x1, "ms_per_step_eager": ms_eager, "settle_steps": settle,
+            "points_from_depth": from_depth,
             **scaling_fields(args, value, world, dist.get_world_size() if dist is not None else 1, per_rank),
             "config": {"workload": f"{args.workload}: {B}x{H}x{W} per GPU, L={cfg['L']} depth layers, "
                                    f"{cfg['K']}x{cfg['K']} '{args.psf_kind}' PSFs, pose theta<={cfg['theta_deg']}deg; "

@@ -19,7 +19,7 @@ class LayerGrid(ctypes.Structure):
                 ("n_layers", c_int32)]
 
 
-ABI_VERSION = 210  # FC3D_VERSION of include/fc3d.h this binding was written against (a stale library is refused)
+ABI_VERSION = 211  # FC3D_VERSION of include/fc3d.h this binding was written against (a stale library is refused)
 
 P = c_void_p      # device pointers travel as integers
 I64 = c_int64
@@ -57,6 +57,8 @@ SIGNATURES = {
                                   P, P, P, P, c_int, P]),
     "fc3d_warp_p2c_pose_fwd": (c_int, [P, P, P, I64, I64, I64, I64, P, I64, I64, I64, I64, P, P, I64, c_int, c_int,
                                        c_int, P, P, P, P, c_int, c_int, P, P, P, P]),
+    "fc3d_warp_p2c_pose_depth_fwd": (c_int, [P, P, P, P, P, P, P, P, I64, c_int, c_int, c_int, P, P, P, P, c_int, c_int,
+                                             P, P, P, P]),
     "fc3d_warp_project_splat": (c_int, [P, P, I64, I64, I64, I64, P, P, I64, c_int, c_int, c_int, P, P, c_int, P, P, P]),
     "fc3d_warp_sample": (c_int, [P, P, P, I64, I64, I64, I64, P, c_int, c_int, c_int, P, c_int, P, P, P]),
     "fc3d_points_fwd": (c_int, [P, P, P, P, P, I64, c_int, c_int, c_int, P]),

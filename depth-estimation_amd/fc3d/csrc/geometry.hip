@@ -109,16 +109,35 @@ __global__ void pose_transforms_kernel(const float* __restrict__ pose, const flo
 // ---------------------------------------------------------------------------------------
 // projection
 // ---------------------------------------------------------------------------------------
-enum CoordLayout { kStrided = 0, kPlanarFlat = 1, kPixel4Flat = 2 };
+#ifndef FC3D_SAMP_DBG
+#define FC3D_SAMP_DBG 0       // timing-only builds of the sampling kernel (1: no tap index, 2: no grid store, 4: mask not cleared)
+#endif
+enum CoordLayout { kStrided = 0, kPlanarFlat = 1, kPixel4Flat = 2, kFromDepth = 3 };
 // kPlanarFlat : dense planes, component k of flat pixel p at base[k*sc + p]
 // kPixel4Flat : dense [H][W][4] (what z2pointcloud's permuted view points at): one aligned float4 per pixel
 // kStrided    : any other view; (y, x) are recovered from p
+// kFromDepth  : no stored points at all: base is the depth plane the points were made from and the point of
+//               pixel (x, y) is formed here as points_in_camera_coords stores it, (z rx[x], z ry[y], z 1, 1)
+//               with separately rounded products -- 4 bytes per pixel read instead of 16
 
-template <int LAYOUT, bool NT = false>
-__device__ __forceinline__ void load_coord(const float* __restrict__ base, long sc, long sh, long sw, long p, int W,
-                                           float c[4]) {
-    if (LAYOUT == kPixel4Flat) {
-        const float4 v = ld_pol<NT>(reinterpret_cast<const float4*>(base + p * 4));
+// P = unsigned: the caller vouches for 16 * H * W < 2^32, and the flat layouts then address with a uniform base
+// and a 32-bit lane offset (one instruction instead of three for a 64-bit lane address).
+template <int LAYOUT, bool NT = false, typename P = long>
+__device__ __forceinline__ void load_coord(const float* __restrict__ base, long sc, long sh, long sw, P p, int W,
+                                           float c[4], const float* __restrict__ ray_x = nullptr,
+                                           const float* __restrict__ ray_y = nullptr) {
+    constexpr bool SMALL = sizeof(P) == 4;
+    if (LAYOUT == kFromDepth) {
+        // loads only (ray_x[x], ray_y[y], z): the products wait in finish_coord, so that the loads of all of a
+        // lane's pixels are in flight together
+        const unsigned y = (unsigned)p / (unsigned)W, x = (unsigned)p - y * (unsigned)W;
+        c[0] = ld_at(ray_x, x);
+        c[1] = ld_at(ray_y, y);
+        c[2] = SMALL ? ld_at_pol<NT>(base, (unsigned)p) : ld_pol<NT>(base + p);
+        c[3] = 1.0f;
+    } else if (LAYOUT == kPixel4Flat) {
+        const float4 v = SMALL ? ld_at_pol<NT>(reinterpret_cast<const float4*>(base), (unsigned)p)
+                               : ld_pol<NT>(reinterpret_cast<const float4*>(base + p * 4));
         c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w;
     } else if (LAYOUT == kPlanarFlat) {
 #pragma unroll
@@ -127,6 +146,17 @@ __device__ __forceinline__ void load_coord(const float* __restrict__ base, long 
         const long y = p / W, x = p - y * W;
 #pragma unroll
         for (int k = 0; k < 4; ++k) c[k] = base[k * sc + y * sh + x * sw];
+    }
+}
+
+// what load_coord left to do once the loads have arrived
+template <int LAYOUT>
+__device__ __forceinline__ void finish_coord(float c[4]) {
+    if (LAYOUT == kFromDepth) {
+        const float z = c[2];
+        c[0] = __fmul_rn(z, c[0]);
+        c[1] = __fmul_rn(z, c[1]);
+        c[2] = __fmul_rn(z, 1.0f);
     }
 }
 
@@ -139,7 +169,8 @@ template <int LAYOUT, bool FMA, bool SPLAT, bool POSE = false>
 __global__ __launch_bounds__(NT) void project_kernel(const float* __restrict__ coord, long sb, long sc, long sh,
                                                      long sw, const float* __restrict__ Tm, int H, int W,
                                                      float* __restrict__ grid, uint8_t* __restrict__ mask_u8,
-                                                     PoseArgs pa) {
+                                                     PoseArgs pa, const float* __restrict__ ray_x,
+                                                     const float* __restrict__ ray_y) {
     const int b = blockIdx.y;
     const long HW = (long)H * W;
     const long p0 = lane_first_pixel<false>();
@@ -148,7 +179,7 @@ __global__ __launch_bounds__(NT) void project_kernel(const float* __restrict__ c
 #pragma unroll
     for (int i = 0; i < PPL; ++i) {
         const long p = p0 + 64 * i;
-        if (p < HW) load_coord<LAYOUT, kNtProjLoad>(cb, sc, sh, sw, p, W, c[i]);
+        if (p < HW) load_coord<LAYOUT, kNtProjLoad>(cb, sc, sh, sw, p, W, c[i], ray_x, ray_y);
     }
     // after the coordinate loads were issued: the few words of K and pose arrive under their latency
     float T[16];
@@ -165,6 +196,7 @@ __global__ __launch_bounds__(NT) void project_kernel(const float* __restrict__ c
         const long p = p0 + 64 * i;
         if (p < HW) {
             float gx, gy;
+            finish_coord<LAYOUT>(c[i]);
             project_px<FMA>(T, c[i][0], c[i][1], c[i][2], c[i][3], gx, gy);
             st_pol<kNtProjStore>(go + p, make_float2(gx, gy));
             if (SPLAT) splat_px<uint8_t>(m, gx, gy, W, HW, 0, (uint8_t)1);
@@ -183,23 +215,29 @@ __global__ __launch_bounds__(NT) void warp_sample_kernel(const float* __restrict
                                                          const float* __restrict__ Ip,
                                                          uint8_t* mask_u8, int rezero, int H, int W,
                                                          float* __restrict__ grid, float* __restrict__ out,
-                                                         void* __restrict__ tap_index, int B) {
+                                                         void* __restrict__ tap_index, int B,
+                                                         const float* __restrict__ ray_x,
+                                                         const float* __restrict__ ray_y) {
     const int b = blockIdx.y;
-    const long HW = (long)H * W;
-    const long p0 = lane_first_pixel();
+    // offsets inside an image are 32-bit (the entry point refuses H*W >= 2^29): every access below is a uniform
+    // 64-bit base plus a 32-bit lane offset, which costs one instruction where 64-bit lane addresses cost three
+    const unsigned HW = (unsigned)H * (unsigned)W;
+    const unsigned p0 = (unsigned)lane_first_pixel();
     const float* T = Tm + (long)b * 16;
     const float* cb = coord + (long)b * sb;
     const float* img = Ip + (long)b * HW;
     uint8_t* mk = mask_u8 + (long)b * HW;
     float c[PPL][4];
     float mv[PPL];
+    uint8_t mb[PPL];          // the mask bytes as loaded: converted where they are used, so that no load waits for a conversion
+    // No branch around a load: a pixel past the image reads the last pixel's operands instead (and stores
+    // nothing).  Behind a branch the number of loads in flight is unknown at the join, and the next pixel's
+    // taps would be issued only after this pixel's had returned -- one memory latency per pixel.
 #pragma unroll
     for (int i = 0; i < PPL; ++i) {
-        const long p = p0 + 64 * i;
-        if (p < HW) {
-            load_coord<LAYOUT, kNtSampLoad>(cb, sc, sh, sw, p, W, c[i]);
-            mv[i] = (float)mk[p];
-        }
+        const unsigned pc = min(p0 + 64u * i, HW - 1u);
+        load_coord<LAYOUT, kNtSampLoad>(cb, sc, sh, sw, pc, W, c[i], ray_x, ray_y);
+        mb[i] = ld_at(mk, pc);
     }
     float2* go = reinterpret_cast<float2*>(grid) + (long)b * HW;
     float* oo = out + (long)b * HW;
@@ -207,39 +245,41 @@ __global__ __launch_bounds__(NT) void warp_sample_kernel(const float* __restrict
     Taps t[PPL];
 #pragma unroll
     for (int i = 0; i < PPL; ++i) {
-        const long p = p0 + 64 * i;
-        if (p < HW) {
-            project_px<FMA>(T, c[i][0], c[i][1], c[i][2], c[i][3], gx[i], gy[i]);
-            t[i] = make_taps(gx[i], gy[i], H, W);
-            i00[i] = img[(long)t[i].y0 * W + t[i].x0];
-            i01[i] = img[(long)t[i].y1 * W + t[i].x0];
-            i10[i] = img[(long)t[i].y0 * W + t[i].x1];
-            i11[i] = img[(long)t[i].y1 * W + t[i].x1];
-        }
+        mv[i] = (float)mb[i];
+        finish_coord<LAYOUT>(c[i]);
+        project_px<FMA>(T, c[i][0], c[i][1], c[i][2], c[i][3], gx[i], gy[i]);
+        t[i] = make_taps(gx[i], gy[i], H, W);
+        const unsigned r0 = (unsigned)t[i].y0 * (unsigned)W, r1 = (unsigned)t[i].y1 * (unsigned)W;
+        i00[i] = ld_at(img, r0 + (unsigned)t[i].x0);
+        i01[i] = ld_at(img, r1 + (unsigned)t[i].x0);
+        i10[i] = ld_at(img, r0 + (unsigned)t[i].x1);
+        i11[i] = ld_at(img, r1 + (unsigned)t[i].x1);
     }
 #pragma unroll
     for (int i = 0; i < PPL; ++i) {
-        const long p = p0 + 64 * i;
+        const unsigned p = p0 + 64u * i;
         if (p < HW) {
-            st_pol<kNtSampGrid>(go + p, make_float2(gx[i], gy[i]));
-            st_pol<kNtSampOut>(oo + p, blend(t[i], i00[i], i01[i], i10[i], i11[i]) * mv[i]);
+#if !(FC3D_SAMP_DBG & 2)
+            st_at_pol<kNtSampGrid>(go, p, make_float2(gx[i], gy[i]));
+#endif
+            st_at_pol<kNtSampOut>(oo, p, blend(t[i], i00[i], i01[i], i10[i], i11[i]) * mv[i]);
         }
     }
-    if (rezero) {
+    if (rezero && !(FC3D_SAMP_DBG & 4)) {
         // The mask leaves the launch cleared for its next use.  A wavefront's 64*PPL bytes are read by
         // its own lanes only, and those loads have returned (their values went into the stores above),
         // so a few lanes can clear the run with 16-byte stores; byte stores where the run is ragged.
-        const long run0 = p0 - (threadIdx.x & 63);
-        const int lane = threadIdx.x & 63;
-        if (rezero == 2 && run0 + 64 * PPL <= HW) {
+        const unsigned lane = threadIdx.x & 63;
+        const unsigned run0 = p0 - lane;
+        if (rezero == 2 && run0 + 64u * PPL <= HW) {
             if (lane < 64 * PPL / 16) *reinterpret_cast<uint4*>(mk + run0 + lane * 16) = make_uint4(0u, 0u, 0u, 0u);
         } else {
 #pragma unroll
             for (int i = 0; i < PPL; ++i)
-                if (p0 + 64 * i < HW) mk[p0 + 64 * i] = 0;
+                if (p0 + 64u * i < HW) st_at(mk, p0 + 64u * i, (uint8_t)0);
         }
     }
-    if (tap_index) {   // for the gradient w.r.t. Ip: where this workgroup's pixels sampled the pattern
+    if (tap_index && !(FC3D_SAMP_DBG & 1)) {   // for the gradient w.r.t. Ip: where this workgroup's pixels sampled the pattern
         int bx[PPL], by[PPL];
         bool on[PPL];
 #pragma unroll
@@ -1381,6 +1421,17 @@ static int pick_layout(const float* coord, int64_t sc, int64_t sh, int64_t sw, i
         }                                                                                                  \
     } while (0)
 
+// the two forward kernels of warp_p2c also exist for points formed from the depth plane
+#define FC3D_DISPATCH_LAYOUT_FWD(NAME, KERNEL, layout, fma, ...)                                                 \
+    do {                                                                                                   \
+        if (layout == kFromDepth) {                                                                        \
+            if (fma) FC3D_LAUNCH(NAME, (KERNEL<kFromDepth, true, ##__VA_ARGS__>), g, blk, 0, s, ARGS);     \
+            else FC3D_LAUNCH(NAME, (KERNEL<kFromDepth, false, ##__VA_ARGS__>), g, blk, 0, s, ARGS);        \
+        } else {                                                                                           \
+            FC3D_DISPATCH_LAYOUT(NAME, KERNEL, layout, fma, ##__VA_ARGS__);                                \
+        }                                                                                                  \
+    } while (0)
+
 }  // namespace fc3d
 
 using namespace fc3d;
@@ -1415,7 +1466,8 @@ extern "C" int fc3d_project_fwd(void* stream, const float* coord, int64_t sb, in
     hipStream_t s = (hipStream_t)stream;
     uint8_t* nomask = nullptr;
     const PoseArgs nopose = {};
-#define ARGS coord, (long)sb, (long)sc, (long)sh, (long)sw, T, H, W, grid_out, nomask, nopose
+    const float* noray = nullptr;
+#define ARGS coord, (long)sb, (long)sc, (long)sh, (long)sw, T, H, W, grid_out, nomask, nopose, noray, noray
     FC3D_DISPATCH_LAYOUT("project_fwd", project_kernel, layout, fma, false);
 #undef ARGS
     FC3D_LAUNCH_CHECK();
@@ -1606,21 +1658,22 @@ extern "C" int fc3d_visible_mask(void* stream, const float* grid, int B, int H, 
 static int launch_project_splat(hipStream_t s, const float* coord_p, int64_t p_sb, int64_t p_sc, int64_t p_sh,
                                 int64_t p_sw, float* T_p2c, float* T_c2p, const float* pose, const float* K,
                                 int64_t k_sb, float* inv_out, int B, int H, int W, float* grid_p2c, uint8_t* mask_u8,
-                                int mask_is_clear) {
-    if (!coord_p || !T_p2c || !grid_p2c || !mask_u8 || (pose && (!K || !T_c2p))) return FC3D_EINVAL;
+                                int mask_is_clear, const float* ray_x = nullptr, const float* ray_y = nullptr) {
+    // ray_x / ray_y given: coord_p is the depth plane [B][H][W] the points are formed from (kFromDepth)
+    if (!coord_p || !T_p2c || !grid_p2c || !mask_u8 || (pose && (!K || !T_c2p)) || (!ray_x != !ray_y)) return FC3D_EINVAL;
     if (int e = check_img(B, H, W)) return e;
-    if ((long)H * W >= (1L << 29)) return FC3D_ERANGE;
+    if ((long)H * W >= (1L << 28)) return FC3D_ERANGE;   // the same limit as the sampling launch behind this one
     if (!aligned4(coord_p) || (reinterpret_cast<uintptr_t>(grid_p2c) & 7u)) return FC3D_EALIGN;
     const bool fma = use_fma(H, W);
     dim3 g(cdiv((long)H * W, PX_PER_BLOCK), B), blk(NT);
     if (!mask_is_clear) {
         if (int e = zero_fill(s, mask_u8, (size_t)B * H * W)) return e;
     }
-    const int layout = pick_layout(coord_p, p_sc, p_sh, p_sw, W);
+    const int layout = ray_x ? (int)kFromDepth : pick_layout(coord_p, p_sc, p_sh, p_sw, W);
     const PoseArgs pa = {pose, K, (long)k_sb, T_p2c, T_c2p, inv_out};
-#define ARGS coord_p, (long)p_sb, (long)p_sc, (long)p_sh, (long)p_sw, (const float*)T_p2c, H, W, grid_p2c, mask_u8, pa
-    if (pose) FC3D_DISPATCH_LAYOUT("warp_project_splat", project_kernel, layout, fma, true, true);
-    else FC3D_DISPATCH_LAYOUT("warp_project_splat", project_kernel, layout, fma, true);
+#define ARGS coord_p, (long)p_sb, (long)p_sc, (long)p_sh, (long)p_sw, (const float*)T_p2c, H, W, grid_p2c, mask_u8, pa, ray_x, ray_y
+    if (pose) FC3D_DISPATCH_LAYOUT_FWD("warp_project_splat", project_kernel, layout, fma, true, true);
+    else FC3D_DISPATCH_LAYOUT_FWD("warp_project_splat", project_kernel, layout, fma, true);
 #undef ARGS
     FC3D_LAUNCH_CHECK();
     return FC3D_OK;
@@ -1629,20 +1682,21 @@ static int launch_project_splat(hipStream_t s, const float* coord_p, int64_t p_s
 // 2. projection of coord_c, sampling of Ip, compositing with the mask (and the tap index on the side)
 static int launch_warp_sample(hipStream_t s, const float* Ip, const float* coord_c, int64_t c_sb, int64_t c_sc,
                               int64_t c_sh, int64_t c_sw, const float* T_c2p, int B, int H, int W, uint8_t* mask_u8,
-                              int mask_rezero, float* Ic_masked, float* grid_c2p, void* tap_index) {
-    if (!Ip || !coord_c || !T_c2p || !Ic_masked || !grid_c2p || !mask_u8) return FC3D_EINVAL;
+                              int mask_rezero, float* Ic_masked, float* grid_c2p, void* tap_index,
+                              const float* ray_x = nullptr, const float* ray_y = nullptr) {
+    if (!Ip || !coord_c || !T_c2p || !Ic_masked || !grid_c2p || !mask_u8 || (!ray_x != !ray_y)) return FC3D_EINVAL;
     if (int e = check_img(B, H, W)) return e;
-    if ((long)H * W >= (1L << 29)) return FC3D_ERANGE;   // per-image byte offsets of the taps are 32-bit
+    if ((long)H * W >= (1L << 28)) return FC3D_ERANGE;   // per-image byte offsets (16 B per pixel for the points) are 32-bit
     if (tap_index && (!gather_fits(H, W, H, W) || (reinterpret_cast<uintptr_t>(tap_index) & 7u))) return FC3D_ERANGE;
     if (!aligned4(coord_c) || !aligned4(Ip) || !aligned4(Ic_masked) || (reinterpret_cast<uintptr_t>(grid_c2p) & 7u))
         return FC3D_EALIGN;
     const bool fma = use_fma(H, W);
     dim3 g(cdiv((long)H * W, PX_PER_BLOCK), B), blk(NT);
-    const int layout = pick_layout(coord_c, c_sc, c_sh, c_sw, W);
+    const int layout = ray_x ? (int)kFromDepth : pick_layout(coord_c, c_sc, c_sh, c_sw, W);
     // 2: runs of 64*PPL bytes start 16-byte aligned in every image, so they can be cleared with 16-byte stores
     const int rezero = !mask_rezero ? 0 : ((aligned16(mask_u8) && ((long)H * W) % 16 == 0) ? 2 : 1);
-#define ARGS coord_c, (long)c_sb, (long)c_sc, (long)c_sh, (long)c_sw, T_c2p, Ip, mask_u8, rezero, H, W, grid_c2p, Ic_masked, tap_index, B
-    FC3D_DISPATCH_LAYOUT("warp_sample", warp_sample_kernel, layout, fma);
+#define ARGS coord_c, (long)c_sb, (long)c_sc, (long)c_sh, (long)c_sw, T_c2p, Ip, mask_u8, rezero, H, W, grid_c2p, Ic_masked, tap_index, B, ray_x, ray_y
+    FC3D_DISPATCH_LAYOUT_FWD("warp_sample", warp_sample_kernel, layout, fma);
 #undef ARGS
     FC3D_LAUNCH_CHECK();
     return FC3D_OK;
@@ -1691,6 +1745,21 @@ extern "C" int fc3d_warp_p2c_pose_fwd(void* stream, const float* Ip, const float
         return e;
     return launch_warp_sample(s, Ip, coord_c, c_sb, c_sc, c_sh, c_sw, T_c2p_out, B, H, W, mask_u8, mask_rezero, Ic_masked,
                               grid_c2p, tap_index);
+}
+
+extern "C" int fc3d_warp_p2c_pose_depth_fwd(void* stream, const float* Ip, const float* z_p, const float* z_c,
+                                            const float* ray_x, const float* ray_y, const float* pose, const float* K,
+                                            int64_t k_sb, int B, int H, int W, float* Ic_masked, float* grid_p2c,
+                                            float* grid_c2p, uint8_t* mask_u8, int mask_is_clear, int mask_rezero,
+                                            void* tap_index, float* T_p2c_out, float* T_c2p_out, float* inv_out) {
+    if (!pose || !K || !Ip || !z_p || !z_c || !ray_x || !ray_y || !Ic_masked || !grid_c2p) return FC3D_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t HW = (int64_t)H * W;
+    if (int e = launch_project_splat(s, z_p, HW, 0, 0, 0, T_p2c_out, T_c2p_out, pose, K, k_sb, inv_out, B, H, W, grid_p2c,
+                                     mask_u8, mask_is_clear, ray_x, ray_y))
+        return e;
+    return launch_warp_sample(s, Ip, z_c, HW, 0, 0, 0, T_c2p_out, B, H, W, mask_u8, mask_rezero, Ic_masked, grid_c2p,
+                              tap_index, ray_x, ray_y);
 }
 
 extern "C" int fc3d_points_fwd(void* stream, const float* z, const float* ray_x, const float* ray_y,

@@ -251,6 +251,45 @@ def _coord_args(coord: torch.Tensor):
     return coord, st
 
 
+# Scene points that are known to be points_in_camera_coords(z, separable pixel rays) carry a note that says
+# so: (the dense depth tensor, its version, ray_x, ray_y, the points' own version).  warp_p2c then reads the
+# 4-byte depth instead of the 16-byte stored point and forms the point as it was stored (bit-identical).  The
+# note is honoured only while neither tensor has been written in place since (version counters) and only for
+# the plain permuted view of the points that the reference's callers pass (geometry_pytorch.py:225-235).
+_POINTS_FROM_DEPTH = True
+
+
+def set_points_from_depth(on: bool) -> bool:
+    """Switches the depth-plane form of warp_p2c's coordinate reads on or off (default on); returns the
+    previous setting."""
+    global _POINTS_FROM_DEPTH
+    old, _POINTS_FROM_DEPTH = _POINTS_FROM_DEPTH, bool(on)
+    return old
+
+
+def note_points_from_depth(points: torch.Tensor, z_dense: torch.Tensor, ray_x: torch.Tensor, ray_y: torch.Tensor):
+    points._fc3d_points = (z_dense, z_dense._version, ray_x, ray_y, points._version)
+
+
+def _points_note(coord: torch.Tensor):
+    """(z [B,H,W,1] dense, ray_x, ray_y) if coord is the untouched [B,4,H,W] view of noted points, else None."""
+    if not _POINTS_FROM_DEPTH or coord.requires_grad:
+        return None
+    base = coord._base if coord._base is not None else coord
+    note = getattr(base, "_fc3d_points", None)
+    if note is None:
+        return None
+    z, zv, rx, ry, pv = note
+    if base._version != pv or z._version != zv or base.dim() != 4 or not base.is_contiguous():
+        return None
+    B, H, W, C = base.shape
+    if C != 4 or tuple(coord.shape) != (B, 4, H, W) or coord.stride() != (H * W * 4, 1, W * 4, 4):
+        return None
+    if coord.data_ptr() != base.data_ptr() or tuple(z.shape) != (B, H, W, 1):
+        return None
+    return z, rx, ry
+
+
 class ProjectFn(torch.autograd.Function):
     """coord_transform; geometry_pytorch.py:68-90."""
 
@@ -533,9 +572,13 @@ class WarpP2CPoseFn(torch.autograd.Function):
     kernel then stores zeros back and the buffer is reused by the next call without a clear.
     Returns (Ic_masked, grid_p2c, grid_c2p)."""
 
+    last_form = None      # "depth" / "points": which coordinate read the last forward used (for tests and benchmarks)
+
     @staticmethod
     def forward(ctx, Ip, coord_p, coord_c, pose, K):
         dev = _need_gpu(Ip, coord_p, coord_c, pose, K)
+        note_p, note_c = _points_note(coord_p), _points_note(coord_c)
+        depth_form = (note_p is not None and note_c is not None and note_p[1] is note_c[1] and note_p[2] is note_c[2])
         coord_p, sp = _coord_args(coord_p)
         coord_c, sc = _coord_args(coord_c)
         B, _, H, W = coord_p.shape
@@ -562,14 +605,22 @@ class WarpP2CPoseFn(torch.autograd.Function):
             pooled = mask is not None
             if not pooled:
                 mask = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
-            status = _lib.fc3d_warp_p2c_pose_fwd(
-                s, ip.data_ptr(), coord_p.data_ptr(), sp[0], sp[1], sp[2], sp[3], coord_c.data_ptr(), sc[0], sc[1],
-                sc[2], sc[3], po.data_ptr(), K.data_ptr(), k_sb, B, H, W, Ic.data_ptr(), gp2c.data_ptr(),
-                gc2p.data_ptr(), mask.data_ptr(), int(pooled), int(pooled),
-                index.data_ptr() if index is not None else None, tt[0].data_ptr(), tt[1].data_ptr(), None)
+            if depth_form:
+                status = _lib.fc3d_warp_p2c_pose_depth_fwd(
+                    s, ip.data_ptr(), note_p[0].data_ptr(), note_c[0].data_ptr(), note_p[1].data_ptr(),
+                    note_p[2].data_ptr(), po.data_ptr(), K.data_ptr(), k_sb, B, H, W, Ic.data_ptr(), gp2c.data_ptr(),
+                    gc2p.data_ptr(), mask.data_ptr(), int(pooled), int(pooled),
+                    index.data_ptr() if index is not None else None, tt[0].data_ptr(), tt[1].data_ptr(), None)
+            else:
+                status = _lib.fc3d_warp_p2c_pose_fwd(
+                    s, ip.data_ptr(), coord_p.data_ptr(), sp[0], sp[1], sp[2], sp[3], coord_c.data_ptr(), sc[0], sc[1],
+                    sc[2], sc[3], po.data_ptr(), K.data_ptr(), k_sb, B, H, W, Ic.data_ptr(), gp2c.data_ptr(),
+                    gc2p.data_ptr(), mask.data_ptr(), int(pooled), int(pooled),
+                    index.data_ptr() if index is not None else None, tt[0].data_ptr(), tt[1].data_ptr(), None)
             if status != 0 and pooled:
                 _zero_masks.pop(key, None)        # its contents are unknown now
-            _check(status, "fc3d_warp_p2c_pose_fwd")
+            _check(status, "fc3d_warp_p2c_pose_depth_fwd" if depth_form else "fc3d_warp_p2c_pose_fwd")
+        WarpP2CPoseFn.last_form = "depth" if depth_form else "points"
         ctx.save_for_backward(gc2p, None if pooled else mask, index, ip if index is not None else None)
         ctx.mark_non_differentiable(gp2c, gc2p)
         ctx.set_materialize_grads(False)

@@ -90,7 +90,11 @@ def points_in_camera_coords(z_map, pixel_to_ray_array, allBatch=False):
     reg = _ray_registry.get(id(rays))
     if reg is not None and reg[0]() is rays:
         rx, ry = _separable_rays(reg[1], reg[2], z_map.device)
-        return _ops.PointsFn.apply(z_map, rx, ry, None)
+        pts = _ops.PointsFn.apply(z_map, rx, ry, None)
+        if z_map.dim() == 4 and z_map.is_contiguous() and z_map.dtype == torch.float32:
+            # what warp_p2c needs to read the depth plane instead of these points (see fc3d.ops)
+            _ops.note_points_from_depth(pts, z_map.detach(), rx, ry)
+        return pts
     dense = torch.from_numpy(np.ascontiguousarray(rays)).float().to(z_map.device)
     return _ops.PointsFn.apply(z_map, None, None, dense)
 

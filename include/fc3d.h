@@ -36,7 +36,7 @@ extern "C" {
 #define FC3D_EALIGN (-3)     /* pointer not aligned to its element type */
 #define FC3D_ESCRATCH (-4)   /* problem larger than the library's static scratch buffer */
 
-#define FC3D_VERSION 210
+#define FC3D_VERSION 211
 
 int fc3d_version(void);
 const char *fc3d_status_string(int status);
@@ -246,6 +246,20 @@ int fc3d_warp_p2c_pose_fwd(void *stream, const float *Ip,
                            float *Ic_masked, float *grid_p2c, float *grid_c2p, uint8_t *mask_u8,
                            int mask_is_clear, int mask_rezero, void *tap_index,
                            float *T_p2c_out, float *T_c2p_out, float *inv_out);
+
+/* fc3d_warp_p2c_pose_fwd for scene points that are points_in_camera_coords of a depth map
+ * (geometry_pytorch.py:44-65 feeding :255-281, as z2pointcloud :225-235 and every caller in
+ * train_pytorch.py produce them): instead of the stored points [B][4][H][W], 16 bytes per pixel and
+ * warp, the kernels read the depth planes z_p, z_c [B][H][W] they were made from and form each point
+ * as it was stored, (z ray_x[x], z ray_y[y], z 1, 1) with separately rounded products (ray_x [W],
+ * ray_y [H]: the separable pixel rays of geometry_pytorch.py:14-41).  Results are bit-identical to
+ * the stored-points form; everything else as in fc3d_warp_p2c_pose_fwd.                         */
+int fc3d_warp_p2c_pose_depth_fwd(void *stream, const float *Ip, const float *z_p, const float *z_c,
+                                 const float *ray_x, const float *ray_y,
+                                 const float *pose, const float *K, int64_t k_sb, int B, int H, int W,
+                                 float *Ic_masked, float *grid_p2c, float *grid_c2p, uint8_t *mask_u8,
+                                 int mask_is_clear, int mask_rezero, void *tap_index,
+                                 float *T_p2c_out, float *T_c2p_out, float *inv_out);
 
 /* The two launches of fc3d_warp_p2c_pose_fwd on their own, for callers that issue them apart -- the
  * first (geometry_pytorch.py:276-277 with :103-104: projection of coord_p and the visibility splat)

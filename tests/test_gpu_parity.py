@@ -573,6 +573,60 @@ def test_warp_pose_in_kernel_matches_separate_transforms(mods, golden, monkeypat
     assert int(mask.count_nonzero()) > 0            # mask_rezero = 0: the mask stays available
 
 
+def test_warp_reads_the_depth_plane_behind_noted_points(mods, monkeypatch):
+    """Scene points made by points_in_camera_coords carry a note of the depth map and rays they came from;
+    warp_p2c then reads 4 bytes of depth per pixel instead of the 16-byte point and forms the point as it was
+    stored.  Every output and the pattern gradient equal the stored-points form bit for bit; the note is dropped
+    as soon as the points or the depth map were written in place, and for anything but the plain permuted view."""
+    G, ops, synth = mods["G"], mods["ops"], mods["synth"]
+    B, H, W = 3, 70, 93
+    monkeypatch.setattr(G, "get_intrinsic", patched_K(W / 2, H / 2))
+    sc = synth.make_scene(B, H, W, seed=41, theta_deg=12.0, t_max=(0.1, 0.1, 0.04))
+    rays = G.pixel_to_ray_array(W, H)
+    z_p, z_c, pose = dev(sc["z_p"]), dev(sc["z_c"]), dev(sc["pose_p2c"])
+    rs = np.random.RandomState(42)
+    ip0 = rs.uniform(0, 1, (B, H, W, 1)).astype(np.float32)
+    gg = dev(rs.uniform(-1, 1, (B, H, W, 1)).astype(np.float32))
+
+    def run(cp, cc):
+        ip = dev(ip0).requires_grad_(True)
+        Ic, gp2c, gc2p = G.warp_p2c(ip, cp, cc, pose)
+        Ic.backward(gg)
+        return (Ic.detach(), gp2c, gc2p, ip.grad), ops.WarpP2CPoseFn.last_form
+
+    def points(z):
+        return G.points_in_camera_coords(z, rays).permute(0, 3, 1, 2)
+
+    cp, cc = points(z_p), points(z_c)
+    got, form = run(cp, cc)
+    assert form == "depth"
+    old = ops.set_points_from_depth(False)
+    try:
+        want, form = run(cp, cc)
+        assert form == "points"
+    finally:
+        ops.set_points_from_depth(old)
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    # copies and other views carry no note
+    assert run(cp.clone(), cc)[1] == "points"
+    assert run(cp.contiguous(), cc.contiguous())[1] == "points"
+    # the points written in place: their values count, not the depth map's
+    cp2 = points(z_p)
+    cp2._base[..., 2] += 0.01
+    got2, form = run(cp2, cc)
+    assert form == "points"
+    want2, _ = run(cp2.clone(), cc.clone())
+    assert all(torch.equal(a, b) for a, b in zip(got2, want2)) and not torch.equal(got2[1], got[1])
+    # the depth map written in place after the points were made: the points still say what they said
+    z2 = z_p.clone()
+    cp3 = points(z2)
+    z2 += 0.05
+    got3, form = run(cp3, cc)
+    assert form == "points"
+    assert all(torch.equal(a, b) for a, b in zip(got3, got))
+
+
 def test_two_stream_warp_loop_needs_only_the_forward_wait(mods):
     """An eager loop that issues the first half of warp_p2c on a side stream and orders ONLY
     main.wait_stream(side) before the second half, as the docstring asks: the side stream runs ahead and would

@@ -21,7 +21,7 @@ def test_cabi_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in fc3d.h but not exported"
     assert declared == set(_native.SIGNATURES), declared ^ set(_native.SIGNATURES)
-    assert lib.fc3d_version() == _native.ABI_VERSION == 210
+    assert lib.fc3d_version() == _native.ABI_VERSION == 211
     assert lib.fc3d_status_string(-1).decode().startswith("invalid")
     # argument validation happens before any device work
     assert lib.fc3d_visible_mask(None, None, 1, 4, 4, 0, None, None) == -1
