@@ -158,16 +158,17 @@ __global__ __launch_bounds__(NT) void capture_sample_kernel(const float* __restr
     const float* img = Ip + (long)b * HW;
     const float* zp = z_p + (long)b * HW;
     const uint8_t* mk = mask_u8 + (long)b * HW;
+    // No branch around a load (a pixel past the image reads the last pixel's operands and stores nothing):
+    // behind a branch the loads in flight are unknown at the join, and the next pixel's taps would wait for
+    // this pixel's to return.
     float z[PPL], mv[PPL], gn[PPL];
+    uint8_t mb[PPL];
 #pragma unroll
     for (int i = 0; i < PPL; ++i) {
-        const long p = p0 + 64 * i;
-        gn[i] = 0.0f;
-        if (p < HW) {
-            z[i] = ld_pol<kNtCapDepth>(zb + p);
-            mv[i] = (float)mk[p];
-            if (peak_partial) gn[i] = gauss[(long)b * HW + p];
-        }
+        const long pc = min(p0 + 64 * i, HW - 1);
+        z[i] = ld_pol<kNtCapDepth>(zb + pc);
+        mb[i] = mk[pc];
+        gn[i] = peak_partial ? gauss[(long)b * HW + pc] : 0.0f;
     }
     extern __shared__ float ray_lds[];    // [W] ray_x, then [H] ray_y
     const float* ray_x = ray_x_g;
@@ -183,19 +184,18 @@ __global__ __launch_bounds__(NT) void capture_sample_kernel(const float* __restr
     Taps t[PPL];
 #pragma unroll
     for (int i = 0; i < PPL; ++i) {
-        const long p = p0 + 64 * i;
-        if (p < HW) {
-            float c[4];
-            point_of(z[i], ray_x, ray_y, (unsigned)p, (unsigned)W, c);
-            project_px<FMA>(T, c[0], c[1], c[2], c[3], gx[i], gy[i]);
-            t[i] = make_taps(gx[i], gy[i], H, W);
-            const unsigned a00 = (unsigned)t[i].y0 * W + t[i].x0, a01 = (unsigned)t[i].y1 * W + t[i].x0;
-            const unsigned a10 = (unsigned)t[i].y0 * W + t[i].x1, a11 = (unsigned)t[i].y1 * W + t[i].x1;
-            i00[i] = ld_at(img, a00); i01[i] = ld_at(img, a01); i10[i] = ld_at(img, a10); i11[i] = ld_at(img, a11);
-            z00[i] = ld_at(zp, a00); z01[i] = ld_at(zp, a01); z10[i] = ld_at(zp, a10); z11[i] = ld_at(zp, a11);
-            rx0[i] = ray_x[t[i].x0]; rx1[i] = ray_x[t[i].x1];
-            ry0[i] = ray_y[t[i].y0]; ry1[i] = ray_y[t[i].y1];
-        }
+        const long pc = min(p0 + 64 * i, HW - 1);
+        mv[i] = (float)mb[i];
+        float c[4];
+        point_of(z[i], ray_x, ray_y, (unsigned)pc, (unsigned)W, c);
+        project_px<FMA>(T, c[0], c[1], c[2], c[3], gx[i], gy[i]);
+        t[i] = make_taps(gx[i], gy[i], H, W);
+        const unsigned a00 = (unsigned)t[i].y0 * W + t[i].x0, a01 = (unsigned)t[i].y1 * W + t[i].x0;
+        const unsigned a10 = (unsigned)t[i].y0 * W + t[i].x1, a11 = (unsigned)t[i].y1 * W + t[i].x1;
+        i00[i] = ld_at(img, a00); i01[i] = ld_at(img, a01); i10[i] = ld_at(img, a10); i11[i] = ld_at(img, a11);
+        z00[i] = ld_at(zp, a00); z01[i] = ld_at(zp, a01); z10[i] = ld_at(zp, a10); z11[i] = ld_at(zp, a11);
+        rx0[i] = ray_x[t[i].x0]; rx1[i] = ray_x[t[i].x1];
+        ry0[i] = ray_y[t[i].y0]; ry1[i] = ray_y[t[i].y1];
     }
     float2* go = grid ? reinterpret_cast<float2*>(grid) + (long)b * HW : nullptr;
     float* oo = Ic + (long)b * HW;
