@@ -330,7 +330,8 @@ def main():
                 fc3d_ops.set_points_from_depth(True)
                 try:
                     gd = GraphedImageFormation(tens["pat"], tens["z_p"], tens["coord_p"], tens["coord_c"], tens["pose"],
-                                               tens["g"], tens["L"], unroll=unroll, overlap=args.overlap)
+                                               tens["g"], tens["L"], unroll=unroll, overlap=args.overlap,
+                                               points_from_depth=True)
                     gd_form = fc3d_ops.WarpP2CPoseFn.last_form
                 except Exception as e:
                     gd, gd_form = None, f"{type(e).__name__}: {e}"

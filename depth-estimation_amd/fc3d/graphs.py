@@ -28,12 +28,16 @@ class GraphedImageFormation:
     forward results (also static)."""
 
     def __init__(self, pattern, z_p, coord_p, coord_c, pose, upstream_grad, n_layers, is_conv_psf=True,
-                 warmup: int = 3, unroll: int = 1, overlap: bool = False):
+                 warmup: int = 3, unroll: int = 1, overlap: bool = False, points_from_depth: bool = False):
         """unroll > 1 additionally captures that many consecutive steps as ONE graph (same launches on
         the same static buffers, back to back), for callers that run many steps on unchanged inputs
         (benchmarks): `replay_steps(k)` then issues k // unroll launches of it plus k % unroll of the
         single step, which takes the pause between two graph launches out of all but a few steps.
-        overlap=True captures warp_p2c's projection + splat launch as a second branch beside codePattern."""
+        overlap=True captures warp_p2c's projection + splat launch as a second branch beside codePattern.
+        points_from_depth=True: coord_p / coord_c that carry the note of points_in_camera_coords are captured in
+        their depth-plane form (the kernels read the depth maps the points were made from).  The graph's inputs
+        are then those depth tensors, not the point tensors: refresh THEM in place between replays; writing new
+        points into coord_p / coord_c has no effect on such a graph."""
         if not (pattern.is_leaf and pattern.requires_grad):
             raise ValueError("pattern must be a leaf tensor that requires grad")
         self.pattern, self.z_p, self.coord_p, self.coord_c, self.pose = pattern, z_p, coord_p, coord_c, pose
@@ -44,7 +48,12 @@ class GraphedImageFormation:
         self.graph_n = None
         # overlap: warp_p2c's first launch runs beside codePattern on a second stream (see _step)
         self.fork = torch.cuda.Stream(device=pattern.device) if overlap else None
-        self._capture(warmup)
+        from fc3d import ops as _ops
+        old = _ops.allow_points_from_depth_in_capture(bool(points_from_depth))
+        try:
+            self._capture(warmup)
+        finally:
+            _ops.allow_points_from_depth_in_capture(old)
 
     def _step(self):
         if self.fork is None:

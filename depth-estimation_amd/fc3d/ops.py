@@ -257,6 +257,16 @@ def _coord_args(coord: torch.Tensor):
 # note is honoured only while neither tensor has been written in place since (version counters) and only for
 # the plain permuted view of the points that the reference's callers pass (geometry_pytorch.py:225-235).
 _POINTS_FROM_DEPTH = True
+# Under stream capture the note cannot be checked again at replay: a graph whose inputs are refreshed in place
+# (coords.copy_(new points)) would go on reading the depth map of the capture.  So a capture uses the stored
+# points unless its owner says that the depth maps are its inputs (GraphedImageFormation(points_from_depth=True)).
+_POINTS_FROM_DEPTH_IN_CAPTURE = False
+
+
+def allow_points_from_depth_in_capture(on: bool) -> bool:
+    global _POINTS_FROM_DEPTH_IN_CAPTURE
+    old, _POINTS_FROM_DEPTH_IN_CAPTURE = _POINTS_FROM_DEPTH_IN_CAPTURE, bool(on)
+    return old
 
 
 def set_points_from_depth(on: bool) -> bool:
@@ -274,6 +284,8 @@ def note_points_from_depth(points: torch.Tensor, z_dense: torch.Tensor, ray_x: t
 def _points_note(coord: torch.Tensor):
     """(z [B,H,W,1] dense, ray_x, ray_y) if coord is the untouched [B,4,H,W] view of noted points, else None."""
     if not _POINTS_FROM_DEPTH or coord.requires_grad:
+        return None
+    if not _POINTS_FROM_DEPTH_IN_CAPTURE and coord.is_cuda and torch.cuda.is_current_stream_capturing():
         return None
     base = coord._base if coord._base is not None else coord
     note = getattr(base, "_fc3d_points", None)

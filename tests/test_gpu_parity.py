@@ -625,6 +625,27 @@ def test_warp_reads_the_depth_plane_behind_noted_points(mods, monkeypatch):
     got3, form = run(cp3, cc)
     assert form == "points"
     assert all(torch.equal(a, b) for a, b in zip(got3, got))
+    # a stream capture cannot re-check the note at replay: it reads the stored points unless its owner opts in
+    Kc = G.get_intrinsic(B)                                         # (no host-to-device copy inside the capture)
+    monkeypatch.setattr(G, "get_intrinsic", lambda B_, device="cuda": Kc)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    ipc = dev(ip0)
+    with torch.cuda.stream(side):
+        G.warp_p2c(ipc, cp, cc, pose)
+    torch.cuda.synchronize()
+    for allow, expect in ((False, "points"), (True, "depth")):
+        old = ops.allow_points_from_depth_in_capture(allow)
+        try:
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=side, capture_error_mode="thread_local"):
+                Icg, _, gcg = G.warp_p2c(ipc, cp, cc, pose)
+            assert ops.WarpP2CPoseFn.last_form == expect
+        finally:
+            ops.allow_points_from_depth_in_capture(old)
+        gr.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(Icg, got[0]) and torch.equal(gcg, got[2])
 
 
 def test_two_stream_warp_loop_needs_only_the_forward_wait(mods):
