@@ -11,7 +11,10 @@ constexpr int NT = 256;
 // Every lane owns PPL pixels that are 64 apart inside its wavefront's run of 64*PPL consecutive
 // pixels, so each load/store/gather instruction of a wavefront touches 64 neighbouring pixels.
 // Two per lane measured best at 32x512x512 (4: 45/54 us for projection/sampling, 2: 41/50, 1: 43/52).
-constexpr int PPL = 2;
+#ifndef FC3D_PPL
+#define FC3D_PPL 2
+#endif
+constexpr int PPL = FC3D_PPL;
 constexpr int PX_PER_BLOCK = NT * PPL;
 
 // XCD: renumber the workgroups so that each XCD walks through a contiguous part of the image.  It pays
