@@ -614,6 +614,15 @@ constexpr int G_WIN = GWR * GWS;                 // window cells
 // waits a turn.
 __device__ __forceinline__ void window_add4_hashed(lds_vfloat win, lds_vu8 own, int c, int ww, float v00, float v10,
                                                    float v01, float v11, bool active, int lane) {
+#if FC3D_GDBG & 8
+    if (active) {               // timing only: no election (wrong where two lanes share a base cell)
+        win[c] = win[c] + v00;
+        win[c + 1] = win[c + 1] + v10;
+        win[c + ww] = win[c + ww] + v01;
+        win[c + ww + 1] = win[c + ww + 1] + v11;
+    }
+    return;
+#endif
     bool pend = active;
     const int slot = c & (G_OWN - 1);
     do {
