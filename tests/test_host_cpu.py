@@ -442,3 +442,38 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_native, "LIB_PATH", os.path.join(ROOT, "does", "not", "exist", "libfc3d_hip.so"))
     with pytest.raises(ImportError, match="no fallback"):
         _native.load()
+
+
+def test_points_note_is_dropped_when_it_no_longer_holds():
+    """The note that lets warp_p2c read a depth map instead of the points made from it (host logic only, CPU
+    tensors): honoured for the plain permuted view of untouched points, dropped for copies, other views,
+    in-place writes to either tensor, points that require a gradient, and when switched off."""
+    import torch
+    from fc3d import ops
+    B, H, W = 2, 5, 7
+    z = torch.rand(B, H, W, 1)
+    rx, ry = torch.rand(W), torch.rand(H)
+    pts = torch.rand(B, H, W, 4)
+    ops.note_points_from_depth(pts, z, rx, ry)
+    view = pts.permute(0, 3, 1, 2)
+    got = ops._points_note(view)
+    assert got is not None and got[0] is z and got[1] is rx and got[2] is ry
+    assert ops._points_note(view.clone()) is None and ops._points_note(view.contiguous()) is None
+    assert ops._points_note(view[:, :, 1:]) is None and ops._points_note(pts.permute(0, 3, 2, 1)) is None
+    old = ops.set_points_from_depth(False)
+    try:
+        assert ops._points_note(view) is None
+    finally:
+        ops.set_points_from_depth(old)
+    assert ops._points_note(view) is not None
+    z.add_(1.0)                                   # the depth map changed after the points were made
+    assert ops._points_note(view) is None
+    pts2 = torch.rand(B, H, W, 4)
+    ops.note_points_from_depth(pts2, z, rx, ry)
+    v2 = pts2.permute(0, 3, 1, 2)
+    assert ops._points_note(v2) is not None
+    pts2[..., 0] *= 2.0                           # the points were edited
+    assert ops._points_note(v2) is None
+    pts3 = torch.rand(B, H, W, 4, requires_grad=True)
+    ops.note_points_from_depth(pts3, z, rx, ry)
+    assert ops._points_note(pts3.permute(0, 3, 1, 2)) is None
