@@ -120,6 +120,26 @@ __device__ __forceinline__ float2 ld_global(const FC3D_GLOBAL float2* base, unsi
     return make_float2(v.x, v.y);
 }
 
+// two neighbouring elements as one load: elements 2 * pair and 2 * pair + 1 (base aligned to the pair)
+template <bool NT = false>
+__device__ __forceinline__ float2 ld_global_pair(const FC3D_GLOBAL float* base, unsigned pair) {
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    const FC3D_GLOBAL f2v* p = reinterpret_cast<const FC3D_GLOBAL f2v*>(reinterpret_cast<const FC3D_GLOBAL char*>(base) + pair * 8u);
+    f2v v;
+    if constexpr (NT) v = __builtin_nontemporal_load(p);
+    else v = *p;
+    return make_float2(v.x, v.y);
+}
+template <bool NT = false>
+__device__ __forceinline__ float4 ld_global_pair(const FC3D_GLOBAL float2* base, unsigned pair) {
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const FC3D_GLOBAL f4v* p = reinterpret_cast<const FC3D_GLOBAL f4v*>(reinterpret_cast<const FC3D_GLOBAL char*>(base) + pair * 16u);
+    f4v v;
+    if constexpr (NT) v = __builtin_nontemporal_load(p);
+    else v = *p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 // Cache policy of streaming accesses.  A step moves about a gigabyte through a 32 MB L2 and a 256 MB
 // memory-side cache: what is read once (scene points, upstream gradients) or written and not read
 // again by the step (grids, the capture, the pattern gradient) is marked non-temporal, so that it does

@@ -575,7 +575,7 @@ __global__ __launch_bounds__(NT) void bilinear_tap_index_kernel(const float* __r
 }
 
 #ifndef FC3D_GDBG
-#define FC3D_GDBG 0          // timing experiments only: 1 no window adds, 2 no sampling at all, 4 no run / segment scans
+#define FC3D_GDBG 0          // timing experiments only: 1 no window adds, 2 no sampling at all, 4 no run / segment scans, 8 no election, 16 one election round
 #endif
 #ifndef FC3D_GATHER_GY
 #define FC3D_GATHER_GY 12
@@ -636,7 +636,7 @@ __device__ __forceinline__ void window_add4_hashed(lds_vfloat win, lds_vu8 own, 
                 pend = false;
             }
         }
-    } while (__builtin_expect(__ballot(pend) != 0, 0));
+    } while (!(FC3D_GDBG & 16) && __builtin_expect(__ballot(pend) != 0, 0));   // 16, timing only: one round, losers dropped
 }
 
 // The first n candidate segments (ids in cand[], live bits in cbits[]) are sampled and their taps added
@@ -652,6 +652,7 @@ struct GatherTile {
 #ifndef FC3D_GATHER_PIPE
 #define FC3D_GATHER_PIPE 0        // 1: two batches of sample loads in flight, the second issued before the first batch is added (measured slower: 46.6-53 against 45.5 us, registers)
 #endif
+template <bool PAIRS>
 __device__ __noinline__ void gather_drain(const float2* __restrict__ gb, const float* __restrict__ vb, unsigned HWt,
                                           lds_vfloat win, lds_vu8 own, lds_vint cand, lds_vint cbits, int n,
                                           GatherTile tl) {
@@ -661,17 +662,43 @@ __device__ __noinline__ void gather_drain(const float2* __restrict__ gb, const f
     const auto vbu = uniform_global(vb);
     // the loads of one batch: G_DEPTH steps of STEP segments each
     auto issue = [&](GatherSample (&sm)[G_DEPTH], int e0) {
+        if constexpr (PAIRS) {
+            // Two steps share eight segments: a lane loads two neighbouring pixels of one of them (16 + 8 bytes)
+            // and the first step takes the even pixel, the second the odd one.  Neighbouring pixels, which
+            // share a base cell wherever the warp magnifies, then never meet in one election.
+            static_assert(G_DEPTH % 2 == 0, "steps come in pairs");
 #pragma unroll
-        for (int d = 0; d < G_DEPTH; ++d) {
-            const int e = e0 + d * STEP;
-            if (e < n) {
-                const int j = min(e + (lane >> 4), n - 1);
-                const int seg = cand[j], bits = cbits[j];
-                const unsigned p = (unsigned)seg * SEG + (lane & 15);
-                sm[d].live = (e + (lane >> 4) < n) && ((bits >> (lane & 15)) & 1);   // a live pixel lies inside the target image
-                const unsigned q = min(p, HWt - 1u);
-                sm[d].g = ld_global<kNtGatherLoad>(gbu, q);
-                sm[d].v = ld_global<kNtGatherLoad>(vbu, q);
+            for (int pr = 0; pr < G_DEPTH / 2; ++pr) {
+                const int e = e0 + pr * (2 * STEP);
+                if (e < n) {
+                    const int sl = lane >> 3, px = 2 * (lane & 7);
+                    const int j = min(e + sl, n - 1);
+                    const int seg = cand[j], bits = cbits[j];
+                    const unsigned pair = min(((unsigned)seg * SEG + px) >> 1, (HWt >> 1) - 1u);
+                    const float4 g4 = ld_global_pair<kNtGatherLoad>(gbu, pair);
+                    const float2 v2 = ld_global_pair<kNtGatherLoad>(vbu, pair);
+                    const bool in = e + sl < n;
+                    sm[2 * pr].g = make_float2(g4.x, g4.y);
+                    sm[2 * pr].v = v2.x;
+                    sm[2 * pr].live = in && ((bits >> px) & 1);           // a live pixel lies inside the target image
+                    sm[2 * pr + 1].g = make_float2(g4.z, g4.w);
+                    sm[2 * pr + 1].v = v2.y;
+                    sm[2 * pr + 1].live = in && ((bits >> (px + 1)) & 1);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int d = 0; d < G_DEPTH; ++d) {
+                const int e = e0 + d * STEP;
+                if (e < n) {
+                    const int j = min(e + (lane >> 4), n - 1);
+                    const int seg = cand[j], bits = cbits[j];
+                    const unsigned p = (unsigned)seg * SEG + (lane & 15);
+                    sm[d].live = (e + (lane >> 4) < n) && ((bits >> (lane & 15)) & 1);   // a live pixel lies inside the target image
+                    const unsigned q = min(p, HWt - 1u);
+                    sm[d].g = ld_global<kNtGatherLoad>(gbu, q);
+                    sm[d].v = ld_global<kNtGatherLoad>(vbu, q);
+                }
             }
         }
     };
@@ -679,7 +706,7 @@ __device__ __noinline__ void gather_drain(const float2* __restrict__ gb, const f
     auto consume = [&](GatherSample (&sm)[G_DEPTH], int e0) {
 #pragma unroll
         for (int d = 0; d < G_DEPTH; ++d) {
-            if (e0 + d * STEP < n) {
+            if (e0 + (PAIRS ? (d >> 1) * (2 * STEP) : d * STEP) < n) {
                 const float gx = sm[d].g.x, gy = sm[d].g.y, v = sm[d].v;
                 const float fx = floorf(gx), fy = floorf(gy);
                 const bool on = sm[d].live && fx >= tl.fbx0 && fx <= tl.fbx1 && fy >= tl.fby0 && fy <= tl.fby1;
@@ -717,6 +744,7 @@ __device__ __noinline__ void gather_drain(const float2* __restrict__ gb, const f
 #ifdef FC3D_GATHER_WAVES
 __attribute__((amdgpu_waves_per_eu(FC3D_GATHER_WAVES, FC3D_GATHER_WAVES)))
 #endif
+template <bool PAIRS>
 __global__ __launch_bounds__(NT) void bilinear_bwd_img_gather_kernel(
     const float* __restrict__ g_out, const float* __restrict__ grid, void* __restrict__ tap_index, int B, int groups,
     int Hs, int Ws, unsigned HWt, float* __restrict__ g_img, const float* __restrict__ img,
@@ -752,7 +780,7 @@ __global__ __launch_bounds__(NT) void bilinear_bwd_img_gather_kernel(
     // hands the first m candidates to gather_drain and moves the rest (fewer than 64) to the front
     auto drain_front = [&](int& ncand, int m) {
 #if !(FC3D_GDBG & 2)
-        if (m > 0) gather_drain(gb, vb, HWt, win, own, cand, cbits, m, tl);
+        if (m > 0) gather_drain<PAIRS>(gb, vb, HWt, win, own, cand, cbits, m, tl);
 #endif
         const int rest = ncand - m;
         int keep_s = 0, keep_b = 0;
@@ -1585,6 +1613,26 @@ extern "C" int fc3d_bilinear_tap_index(void* stream, const float* grid, const ui
     return launch_tap_index((hipStream_t)stream, grid, mask_u8, B, Hs, Ws, Ht, Wt, index);
 }
 
+#ifndef FC3D_GATHER_PAIRS
+#define FC3D_GATHER_PAIRS 1
+#endif
+// The image-gradient gather: samples are loaded two neighbouring pixels at a time where the target images hold
+// an even number of pixels and the planes are aligned for it (every practical size), one at a time otherwise.
+static int launch_gather(hipStream_t s, const float* g_out, const float* grid, void* index, int B, int Hs, int Ws, int Ht,
+                         int Wt, float* g_img, const float* img, float* dot_partial) {
+    const long HWt = (long)Ht * Wt;
+    const dim3 gridDim3(cdiv(Ws, (NT / 64) * GX), cdiv(Hs, GY), B);
+    const bool pairs = FC3D_GATHER_PAIRS && HWt % 2 == 0 && aligned16(grid) && (reinterpret_cast<uintptr_t>(g_out) & 7u) == 0;
+    if (pairs) {
+        FC3D_LAUNCH("bilinear_bwd_img_gather", bilinear_bwd_img_gather_kernel<true>, gridDim3, dim3(NT), 0, s, g_out, grid, index,
+                    B, (int)tap_index_groups(Ht, Wt), Hs, Ws, (unsigned)HWt, g_img, img, dot_partial);
+    } else {
+        FC3D_LAUNCH("bilinear_bwd_img_gather", bilinear_bwd_img_gather_kernel<false>, gridDim3, dim3(NT), 0, s, g_out, grid, index,
+                    B, (int)tap_index_groups(Ht, Wt), Hs, Ws, (unsigned)HWt, g_img, img, dot_partial);
+    }
+    return FC3D_OK;
+}
+
 extern "C" int fc3d_bilinear_bwd_img(void* stream, const float* g_out, const float* grid, const uint8_t* mask_u8,
                                      int B, int Hs, int Ws, int C, int Ht, int Wt, void* index, int index_ready,
                                      float* g_img) {
@@ -1615,10 +1663,7 @@ extern "C" int fc3d_bilinear_bwd_img(void* stream, const float* g_out, const flo
     if (!index_ready) {
         if (int e = launch_tap_index(s, grid, mask_u8, B, Hs, Ws, Ht, Wt, index)) return e;
     }
-    FC3D_LAUNCH("bilinear_bwd_img_gather", bilinear_bwd_img_gather_kernel, dim3(cdiv(Ws, (NT / 64) * GX), cdiv(Hs, GY), B),
-                dim3(NT), 0, s, g_out, grid, index, B, (int)tap_index_groups(Ht, Wt), Hs, Ws,
-                (unsigned)((long)Ht * Wt), g_img, (const float*)nullptr, (float*)nullptr);
-    return FC3D_OK;
+    return launch_gather(s, g_out, grid, index, B, Hs, Ws, Ht, Wt, g_img, nullptr, nullptr);
 }
 
 extern "C" int fc3d_bilinear_bwd_img_dot_count(int Hs, int Ws) {
@@ -1635,10 +1680,7 @@ extern "C" int fc3d_bilinear_bwd_img_dot(void* stream, const float* g_out, const
     if (!gather_fits(Hs, Ws, Ht, Wt)) return FC3D_ERANGE;
     if ((reinterpret_cast<uintptr_t>(grid) & 7u) || (reinterpret_cast<uintptr_t>(index) & 7u)) return FC3D_EALIGN;
     if (!aligned4(img) || !aligned4(g_img) || !aligned4(dot_partial)) return FC3D_EALIGN;
-    FC3D_LAUNCH("bilinear_bwd_img_gather", bilinear_bwd_img_gather_kernel, dim3(cdiv(Ws, (NT / 64) * GX), cdiv(Hs, GY), B),
-                dim3(NT), 0, (hipStream_t)stream, g_out, grid, index, B, (int)tap_index_groups(Ht, Wt), Hs, Ws,
-                (unsigned)((long)Ht * Wt), g_img, img, dot_partial);
-    return FC3D_OK;
+    return launch_gather((hipStream_t)stream, g_out, grid, index, B, Hs, Ws, Ht, Wt, g_img, img, dot_partial);
 }
 
 extern "C" int fc3d_visible_mask(void* stream, const float* grid, int B, int H, int W, int method, float* mask_f32,
