@@ -71,6 +71,10 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 static inline bool aligned4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0; }
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// The lanes of the wavefront for which `p` holds, as a mask (taken from the comparison that made `p`;
+// __ballot goes through an integer and costs two vector instructions more).
+__device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 // Order-preserving map float -> uint32 (larger float <=> larger key); -0 is folded onto +0
 // so that ties between them are broken by position like torch.max does.
 __device__ __forceinline__ uint32_t float_to_key(float v) {

@@ -597,13 +597,14 @@ constexpr int G_OWN = 256;                    // election slots (cells hash onto
 struct GatherSample {
     float2 g;
     float v;
-    bool live;
+    int live;          // non-zero: the pixel lies inside the target image and is not masked out (an int: flags
+                       // of several samples in flight get packed into bytes, at a dozen instructions per step)
 };
 
 // appends the lanes with `hit` to list[n..] in lane order; returns the new length
 template <typename L, typename V>
 __device__ __forceinline__ int list_append(L list, int n, bool hit, V value, int lane) {
-    const unsigned long long bal = __ballot(hit);
+    const unsigned long long bal = ballot64(hit);
     if (hit) list[n + __popcll(bal & ((1ull << lane) - 1ull))] = value;
     return n + __popcll(bal);
 }
@@ -636,7 +637,7 @@ __device__ __forceinline__ void window_add4_hashed(lds_vfloat win, lds_vu8 own, 
                 pend = false;
             }
         }
-    } while (!(FC3D_GDBG & 16) && __builtin_expect(__ballot(pend) != 0, 0));   // 16, timing only: one round, losers dropped
+    } while (!(FC3D_GDBG & 16) && __builtin_expect(ballot64(pend) != 0, 0));   // 16, timing only: one round, losers dropped
 }
 
 // The first n candidate segments (ids in cand[], live bits in cbits[]) are sampled and their taps added
@@ -646,9 +647,10 @@ __device__ __forceinline__ void window_add4_hashed(lds_vfloat win, lds_vu8 own, 
 // A live sample's corners were not clamped: x0 = floor x, x1 = x0 + 1, and the weights are those
 // of make_taps (x1 - x, x - x0; the corners are exact in fp32).
 struct GatherTile {
-    float fbx0, fbx1, fby0, fby1;     // base cells whose taps reach the tile
-    float fcol0;                      // source column of window column 0
+    float cx, cy;                     // centre of the base cells whose taps reach the tile (GX + 1 columns, GY + 1 rows of them)
 };
+static_assert(GX % 2 == 0 && GY % 2 == 0, "the base cells of a tile need a centre cell");
+constexpr int G_CENTRE = (GY / 2) * GWS + GX / 2 + 3;   // its window cell: tile row 0 is window row 1, tile column 0 window column 4
 #ifndef FC3D_GATHER_PIPE
 #define FC3D_GATHER_PIPE 0        // 1: two batches of sample loads in flight, the second issued before the first batch is added (measured slower: 46.6-53 against 45.5 us, registers)
 #endif
@@ -660,6 +662,7 @@ __device__ __noinline__ void gather_drain(const float2* __restrict__ gb, const f
     const int lane = threadIdx.x & 63;
     const auto gbu = uniform_global(gb);
     const auto vbu = uniform_global(vb);
+    lds_vfloat winc = win + G_CENTRE;
     // the loads of one batch: G_DEPTH steps of STEP segments each
     auto issue = [&](GatherSample (&sm)[G_DEPTH], int e0) {
         if constexpr (PAIRS) {
@@ -669,22 +672,22 @@ __device__ __noinline__ void gather_drain(const float2* __restrict__ gb, const f
             static_assert(G_DEPTH % 2 == 0, "steps come in pairs");
 #pragma unroll
             for (int pr = 0; pr < G_DEPTH / 2; ++pr) {
+                // no branch around the loads (a pair of steps past the end re-reads the last segment and is not
+                // consumed): values that come out of a branch get copied, and the copies wait for the loads
                 const int e = e0 + pr * (2 * STEP);
-                if (e < n) {
-                    const int sl = lane >> 3, px = 2 * (lane & 7);
-                    const int j = min(e + sl, n - 1);
-                    const int seg = cand[j], bits = cbits[j];
-                    const unsigned pair = min(((unsigned)seg * SEG + px) >> 1, (HWt >> 1) - 1u);
-                    const float4 g4 = ld_global_pair<kNtGatherLoad>(gbu, pair);
-                    const float2 v2 = ld_global_pair<kNtGatherLoad>(vbu, pair);
-                    const bool in = e + sl < n;
-                    sm[2 * pr].g = make_float2(g4.x, g4.y);
-                    sm[2 * pr].v = v2.x;
-                    sm[2 * pr].live = in && ((bits >> px) & 1);           // a live pixel lies inside the target image
-                    sm[2 * pr + 1].g = make_float2(g4.z, g4.w);
-                    sm[2 * pr + 1].v = v2.y;
-                    sm[2 * pr + 1].live = in && ((bits >> (px + 1)) & 1);
-                }
+                const int sl = lane >> 3, px = 2 * (lane & 7);
+                const int j = min(e + sl, n - 1);
+                const int seg = cand[j], cb = cbits[j];
+                const int bits = (e + sl < n) ? cb : 0;
+                const unsigned pair = min(((unsigned)seg * SEG + px) >> 1, (HWt >> 1) - 1u);
+                const float4 g4 = ld_global_pair<kNtGatherLoad>(gbu, pair);
+                const float2 v2 = ld_global_pair<kNtGatherLoad>(vbu, pair);
+                sm[2 * pr].g = make_float2(g4.x, g4.y);
+                sm[2 * pr].v = v2.x;
+                sm[2 * pr].live = bits & (1 << px);
+                sm[2 * pr + 1].g = make_float2(g4.z, g4.w);
+                sm[2 * pr + 1].v = v2.y;
+                sm[2 * pr + 1].live = bits & (2 << px);
             }
         } else {
 #pragma unroll
@@ -694,7 +697,7 @@ __device__ __noinline__ void gather_drain(const float2* __restrict__ gb, const f
                     const int j = min(e + (lane >> 4), n - 1);
                     const int seg = cand[j], bits = cbits[j];
                     const unsigned p = (unsigned)seg * SEG + (lane & 15);
-                    sm[d].live = (e + (lane >> 4) < n) && ((bits >> (lane & 15)) & 1);   // a live pixel lies inside the target image
+                    sm[d].live = (e + (lane >> 4) < n) ? bits & (1 << (lane & 15)) : 0;
                     const unsigned q = min(p, HWt - 1u);
                     sm[d].g = ld_global<kNtGatherLoad>(gbu, q);
                     sm[d].v = ld_global<kNtGatherLoad>(vbu, q);
@@ -707,17 +710,22 @@ __device__ __noinline__ void gather_drain(const float2* __restrict__ gb, const f
 #pragma unroll
         for (int d = 0; d < G_DEPTH; ++d) {
             if (e0 + (PAIRS ? (d >> 1) * (2 * STEP) : d * STEP) < n) {
+                // Relative to the centre of the tile's base cells, a sample is the tile's if it lies within half
+                // a tile either way, and its window cell (counted from the centre cell) is one multiply-add.
+                // x1 - x as 1 - (x - x0): x - x0 is exact for x >= 0, so both are the one rounding of x0 + 1 - x.
                 const float gx = sm[d].g.x, gy = sm[d].g.y, v = sm[d].v;
                 const float fx = floorf(gx), fy = floorf(gy);
-                const bool on = sm[d].live && fx >= tl.fbx0 && fx <= tl.fbx1 && fy >= tl.fby0 && fy <= tl.fby1;
-                const float wx1 = __fsub_rn(gx, fx), wx0 = __fsub_rn(__fadd_rn(fx, 1.0f), gx);
-                const float wy1 = __fsub_rn(gy, fy), wy0 = __fsub_rn(__fadd_rn(fy, 1.0f), gy);
-                const int c = on ? (int)(__fsub_rn(fy, tl.fby0) * (float)GWS + __fsub_rn(fx, tl.fcol0)) : 0;
+                const float dx = __fsub_rn(fx, tl.cx), dy = __fsub_rn(fy, tl.cy);
+                const bool on = sm[d].live != 0 && fabsf(dx) <= (float)(GX / 2) && fabsf(dy) <= (float)(GY / 2);
+                const int c = on ? (int)__fadd_rn(__fmul_rn(dy, (float)GWS), dx) : 0;
+                const float wx1 = __fsub_rn(gx, fx), wy1 = __fsub_rn(gy, fy);
+                const fc3d_f2v wx = {__fsub_rn(1.0f, wx1), wx1};
+                const float wy0 = __fsub_rn(1.0f, wy1);
+                const fc3d_f2v r0 = (wx * wy0) * v, r1 = (wx * wy1) * v;      // {v00, v10}, {v01, v11}
 #if FC3D_GDBG & 1
-                if (on && v == 123.456f) win[c] = wx0 * wy0 + wx1 * wy1;
+                if (on && v == 123.456f) winc[c] = r0.x + r1.y;
 #else
-                window_add4_hashed(win, own, c, GWS, (wx0 * wy0) * v, (wx1 * wy0) * v, (wx0 * wy1) * v, (wx1 * wy1) * v, on,
-                                   lane);
+                window_add4_hashed(winc, own, c, GWS, r0.x, r0.y, r1.x, r1.y, on, lane);
 #endif
             }
         }
@@ -776,7 +784,7 @@ __global__ __launch_bounds__(NT) void bilinear_bwd_img_gather_kernel(
     }
 
     GatherTile tl;
-    tl.fbx0 = (float)bx0; tl.fbx1 = (float)bx1; tl.fby0 = (float)by0; tl.fby1 = (float)by1; tl.fcol0 = (float)(sx0 - 4);
+    tl.cx = (float)(bx0 + GX / 2); tl.cy = (float)(by0 + GY / 2);
     // hands the first m candidates to gather_drain and moves the rest (fewer than 64) to the front
     auto drain_front = [&](int& ncand, int m) {
 #if !(FC3D_GDBG & 2)
