@@ -544,30 +544,41 @@ constexpr int kPsfStageMax = 8;      // staged floats per thread: L * KKP <= 8 *
 template <int K>
 struct PsfStage {
     float v[kPsfStageMax];
+    unsigned pad;        // bit u: this thread's slot of round u is padding (of a PSF row or of the layer)
 };
 template <int K>
 __device__ __forceinline__ bool psf_stage_fits(int L) { return L * Roll<K>::KKP <= kPsfStageMax * NT; }
+// (unsigned index arithmetic -- a signed division by a constant costs three times the instructions -- and only
+// the rounds the stack has slots for: at 21 layers of 5x5 three of the eight.  This runs once per workgroup, but a
+// workgroup's strips are short: done the plain way it was a quarter of the kernel's vector instructions.)
 template <int K>
 __device__ __forceinline__ void psf_stage_load(PsfStage<K>& st, const float* __restrict__ psf, int L) {
-    constexpr int KK = Roll<K>::KK, KKP = Roll<K>::KKP, KS = Roll<K>::KS;
-    // unconditional loads from clamped (always valid) addresses: no branch, no wait between them
+    constexpr unsigned KK = Roll<K>::KK, KKP = Roll<K>::KKP, KS = Roll<K>::KS;
+    const unsigned n = (unsigned)L * KKP;
+    st.pad = 0u;
+    // loads from clamped (always valid) addresses, inside wave-uniform branches only
 #pragma unroll
     for (int u = 0; u < kPsfStageMax; ++u) {
-        const int i = min(u * NT + (int)threadIdx.x, L * KKP - 1);
-        const int l = i / KKP, j = i - l * KKP;
-        const int dy = j / KS, dx = j - dy * KS;
-        st.v[u] = ld_at(psf, (unsigned)(l * KK + min(dy, K - 1) * K + min(dx, K - 1)));
+        st.v[u] = 0.0f;
+        if ((unsigned)(u * NT) < n) {
+            const unsigned i = min((unsigned)(u * NT) + threadIdx.x, n - 1u);
+            const unsigned l = i / KKP, j = i - l * KKP;
+            const unsigned dy = j / KS, dx = j - dy * KS;
+            st.pad |= (unsigned)((dy >= (unsigned)K) | (dx >= (unsigned)K)) << u;
+            st.v[u] = ld_at(psf, l * KK + min(dy, (unsigned)(K - 1)) * K + min(dx, (unsigned)(K - 1)));
+        }
     }
 }
 template <int K>
 __device__ __forceinline__ void psf_stage_store(const PsfStage<K>& st, float* __restrict__ wts, int L) {
-    constexpr int KKP = Roll<K>::KKP;
+    constexpr unsigned KKP = Roll<K>::KKP;
+    const unsigned n = (unsigned)L * KKP;
 #pragma unroll
     for (int u = 0; u < kPsfStageMax; ++u) {
-        const int i = u * NT + threadIdx.x;
-        const int j = i % KKP;
-        const bool pad = (j / Roll<K>::KS >= K) || (j % Roll<K>::KS >= K);     // the padding of a row / of the layer
-        if (i < L * KKP) wts[i] = pad ? 0.0f : st.v[u];
+        if ((unsigned)(u * NT) < n) {
+            const unsigned i = (unsigned)(u * NT) + threadIdx.x;
+            if (i < n) wts[i] = ((st.pad >> u) & 1u) ? 0.0f : st.v[u];
+        }
     }
 }
 // a * b for wave-uniform a on the scalar unit, opaque to the compiler: folded into the lane arithmetic that
