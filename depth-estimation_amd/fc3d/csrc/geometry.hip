@@ -584,6 +584,7 @@ constexpr int GX = 64, GY = FC3D_GATHER_GY;   // source tile of one wavefront
 constexpr int GWS = GX + 8;                   // window row stride: tile column 0 at window column 4 (16-byte aligned rows)
 constexpr int GWR = GY + 2;                   // window rows: tile row 0 at window row 1
 constexpr int G_GROUPS = NT * 2;              // group boxes the workgroup scans per round
+constexpr int G_HITCAP = 2 * G_GROUPS / (NT / 64);   // group hits a scanning wavefront can hold: two rounds' worth
 constexpr int G_UNROLL = 2;                   // run-level steps (64 boxes each) whose loads are in flight together
 constexpr int G_RUNS = 64 + 64 * G_UNROLL;    // run list: handed on above 64 entries, one round adds at most 64 * G_UNROLL
 constexpr int G_CAND = 128;                   // candidate segments: drained above 64, one step adds at most 64
@@ -759,7 +760,7 @@ __global__ __launch_bounds__(NT) void bilinear_bwd_img_gather_kernel(
     float* __restrict__ dot_partial) {
     __shared__ __align__(16) float s_win[NT / 64][G_WIN];
     __shared__ uint8_t s_own[NT / 64][G_OWN];
-    __shared__ int s_ghit[NT / 64][G_GROUPS / (NT / 64)];   // groups that meet the workgroup's row of tiles, per scanning wavefront
+    __shared__ uint16_t s_ghit[NT / 64][G_HITCAP];          // groups that meet the workgroup's row of tiles, per scanning wavefront, counted from `cbase`
     __shared__ int s_ng[NT / 64];
     __shared__ int s_rhit[NT / 64][G_RUNS];
     __shared__ int s_cand[NT / 64][2 * G_CAND];             // segment ids, then their live bits
@@ -803,25 +804,35 @@ __global__ __launch_bounds__(NT) void bilinear_bwd_img_gather_kernel(
     // done; every loop runs one extra pass that only flushes, so that each level's code exists once.
     constexpr int GPS = 64 / RUN_PER_GROUP, RPS = 64 / SEG_PER_RUN;   // group hits / run hits whose children fill one step
     constexpr int GPW = G_GROUPS / NT;                                // group steps per wavefront and round
-    int nr = 0, ncand = 0;
+    // Group hits pile up over scan rounds and are worked off (runs -> segments -> samples) when a wavefront's list
+    // might not hold another round, or at the end: an image of many groups (2,048 at 1024 x 1024) costs every
+    // workgroup one chain of dependent loads per level, not one per 512 groups.
+    int nr = 0, ncand = 0, cnt = 0, cbase = 0;
     for (int c0 = 0; c0 < groups; c0 += G_GROUPS) {
         const bool fin_g = c0 + G_GROUPS >= groups;
         int2 gbox[GPW];
 #pragma unroll
         for (int u = 0; u < GPW; ++u) gbox[u] = ix.group[min(c0 + (wv * GPW + u) * 64 + lane, groups - 1)];
-        int cnt = 0;
 #pragma unroll
         for (int u = 0; u < GPW; ++u) {
             const int g = c0 + (wv * GPW + u) * 64 + lane;
-            cnt = list_append(lds_ptr(s_ghit[wv]), cnt, g < groups && box_meets(gbox[u], rbx0, rbx1, by0, by1), g, lane);
+            cnt = list_append(lds_ptr(s_ghit[wv]), cnt, g < groups && box_meets(gbox[u], rbx0, rbx1, by0, by1),
+                              (uint16_t)(g - cbase), lane);
         }
         if (lane == 0) s_ng[wv] = cnt;
         __syncthreads();
-        if (tile_live && !(FC3D_GDBG & 4)) {
-            int off[NT / 64 + 1];
-            off[0] = 0;
+        int off[NT / 64 + 1];
+        off[0] = 0;
+        int most = 0;
 #pragma unroll
-            for (int w2 = 0; w2 < NT / 64; ++w2) off[w2 + 1] = off[w2] + s_ng[w2];
+        for (int w2 = 0; w2 < NT / 64; ++w2) {
+            const int k = s_ng[w2];
+            off[w2 + 1] = off[w2] + k;
+            most = max(most, k);
+        }
+        // the same in every wavefront of the workgroup: all read the same counts
+        const bool flush = fin_g || most > G_HITCAP - GPW * 64 || c0 + 2 * G_GROUPS - cbase > 65536;
+        if (flush && tile_live && !(FC3D_GDBG & 4)) {
             const int ng = off[NT / 64];
             const int rounds_r = (ng + GPS * G_UNROLL - 1) / (GPS * G_UNROLL);
             for (int rr = 0; rr <= rounds_r; ++rr) {
@@ -838,7 +849,7 @@ __global__ __launch_bounds__(NT) void bilinear_bwd_img_gather_kernel(
                         int base = 0;
 #pragma unroll
                         for (int q = 1; q < NT / 64; ++q) base = (w2 == q) ? off[q] : base;
-                        run[u] = lds_ptr(s_ghit[0])[w2 * (G_GROUPS / (NT / 64)) + j - base] * RUN_PER_GROUP + lane % RUN_PER_GROUP;
+                        run[u] = (cbase + (int)lds_ptr(s_ghit[0])[w2 * G_HITCAP + j - base]) * RUN_PER_GROUP + lane % RUN_PER_GROUP;
                         rb[u] = ix.run[run[u]];
                     }
 #pragma unroll
@@ -871,7 +882,11 @@ __global__ __launch_bounds__(NT) void bilinear_bwd_img_gather_kernel(
                 nr = 0;
             }
         }
-        __syncthreads();                              // s_ghit is rewritten by the next round
+        if (flush) {
+            cnt = 0;
+            cbase = c0 + G_GROUPS;
+        }
+        __syncthreads();                              // s_ng (and after a flush s_ghit) is rewritten by the next round
     }
     // dot_partial (with img, the image that was sampled): one value per tile, the sum over the tile of
     // (gradient just formed) * img -- what a normalisation of img by one of its own statistics needs in

@@ -374,7 +374,11 @@ def test_bilinear_golden(mods, golden, mode):
 
 @pytest.mark.parametrize("B,Hs,Ws,Ht,Wt,kind", [
     (2, 37, 53, 37, 53, "smooth"), (1, 20, 70, 33, 41, "random"), (1, 130, 300, 64, 64, "zoom"),
-    (3, 5, 3, 5, 3, "smooth"), (1, 1, 1, 1, 1, "smooth"), (2, 64, 200, 64, 200, "jump"), (1, 96, 520, 40, 1030, "smooth")])
+    (3, 5, 3, 5, 3, "smooth"), (1, 1, 1, 1, 1, "smooth"), (2, 64, 200, 64, 200, "jump"), (1, 96, 520, 40, 1030, "smooth"),
+    # targets of more than 512 index groups (several scan rounds per workgroup): hits that pile up over the rounds
+    # and are worked off once, and -- ten target pixels per source cell -- lists that fill up and are worked off
+    # in between
+    (1, 300, 500, 700, 900, "smooth"), (1, 64, 128, 640, 1024, "zoom")])
 def test_image_gradient_gather_form(mods, B, Hs, Ws, Ht, Wt, kind):
     """d out / d img of the one-channel sampler in gather form (source tiles look up their samples
     in the tap index) against a float64 scatter_add of the four weighted taps: ragged sizes,
