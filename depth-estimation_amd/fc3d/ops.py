@@ -112,7 +112,7 @@ def _offer_grad_dot(grad: torch.Tensor, img: torch.Tensor, partials: torch.Tenso
     handover_stats["offered"] += 1
     if len(_pending_offers) > 64:
         _pending_offers.clear()
-    _pending_offers[img.data_ptr()] = img._version
+    _pending_offers[img.data_ptr()] = (img._version, tuple(img.shape))
 
 
 def _take_grad_dot(grad: torch.Tensor, out: torch.Tensor):
@@ -120,7 +120,7 @@ def _take_grad_dot(grad: torch.Tensor, out: torch.Tensor):
     hit = getattr(grad, "_fc3d_dot", None)
     pending = _pending_offers.pop(out.data_ptr(), None)
     if hit is None:
-        if pending is not None and pending == out._version and grad.is_contiguous():
+        if pending is not None and pending == (out._version, tuple(out.shape)) and grad.is_contiguous():
             # a sum was offered for exactly this image, and the gradient that arrived does not carry it: either
             # autograd summed gradients of several consumers (a new tensor: legitimate) or it no longer passes
             # the producer's tensor object on

@@ -1,0 +1,340 @@
+"""Randomised shape sweep of the image-formation operators against the CPU oracle.
+
+Not collected by pytest (tests/test_gpu_fuzz.py runs a bounded number of its cases); run by hand on
+the GPU box for a longer sweep:
+
+    python tests/fuzz_gpu.py --cases 400 --seed 1
+
+Every case draws a batch, an image size (including sizes below one tile, widths that are not multiples
+of 4, 60 or 64, single rows and columns), a layer count, a PSF size (odd 1..33, even, 'disc' / 'gauss' /
+'rand'), a depth map (noise, ramps, steps, out-of-range values) and a pose, and compares
+
+  codePattern      layer index bit for bit; image and pattern gradient to 1e-4 of the scale
+  warp_p2c         both grids and the visibility mask bit for bit (the oracle is handed the library's
+                   inverse pose); the capture and the gradient w.r.t. the sampled image to 1e-4
+  capture kernels  the fused simulator kernels bit for bit against the operators composed on the GPU
+
+The bars are the ones of tests/test_gpu_parity.py."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "depth-estimation_amd"), os.path.join(ROOT, "oracle"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+TOL = 1e-4
+DEBUG = False
+
+
+def rel_err(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b)) / max(float(np.max(np.abs(b))), 1e-30)) if a.size else 0.0
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def draw_size(rs):
+    kind = rs.randint(6)
+    if kind == 0:
+        return int(rs.randint(1, 9)), int(rs.randint(1, 9))
+    if kind == 1:
+        return 1, int(rs.randint(1, 400))
+    if kind == 2:
+        return int(rs.randint(1, 200)), 1
+    if kind == 3:                                   # around the strip / tile widths of the kernels
+        return int(rs.randint(1, 70)), int(rs.choice([59, 60, 61, 63, 64, 65, 119, 120, 121, 127, 128, 129, 255, 256, 257]))
+    return int(rs.randint(2, 140)), int(rs.randint(2, 300))
+
+
+def draw_depth(rs, B, H, W):
+    kind = rs.randint(5)
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    if kind == 0:
+        z = rs.uniform(0.69, 0.95, (B, H, W))
+    elif kind == 1:                                 # some pixels beyond both ends of the layer range
+        z = rs.uniform(0.66, 0.98, (B, H, W))
+    elif kind == 2:                                 # one layer (or two) per image
+        z = np.broadcast_to(rs.uniform(0.7, 0.94, (B, 1, 1)), (B, H, W)) + rs.uniform(0, 2e-3, (B, H, W))
+    elif kind == 3:                                 # ramps: every tile holds several layers
+        z = 0.7 + 0.24 * ((xx * rs.randint(1, 9) + yy * rs.randint(1, 9)) % 97) / 97.0
+        z = np.broadcast_to(z, (B, H, W))
+    else:                                           # steps
+        z = np.where((xx // max(1, int(rs.randint(1, 40))) + yy // max(1, int(rs.randint(1, 40)))) % 2 == 0,
+                     rs.uniform(0.7, 0.8), rs.uniform(0.85, 0.94))
+        z = np.broadcast_to(z, (B, H, W))
+    return np.ascontiguousarray(z[..., None]).astype(np.float32)
+
+
+def case_code_pattern(rs, env):
+    O, synth, orc, ops = env["O"], env["synth"], env["orc"], env["ops"]
+    B = int(rs.randint(1, 4))
+    H, W = draw_size(rs)
+    L = int(rs.choice([5, 20, 21, 41]))
+    conv = rs.uniform() < 0.85
+    K = int(rs.choice([1, 2, 3, 4, 5, 5, 5, 6, 7, 7, 8, 9, 11, 13, 15, 17, 19, 21, 23, 25, 27, 29, 31, 33]))
+    kind = str(rs.choice(["disc", "gauss", "rand"]))
+    desc = dict(op="codePattern", B=B, H=H, W=W, L=L, K=K, kind=kind, conv=bool(conv))
+    z = draw_depth(rs, B, H, W)
+    p0 = rs.uniform(0, 1, (B, H, W, 1)).astype(np.float32)
+    if rs.uniform() < 0.3:
+        p0 = (p0 > 0.8).astype(np.float32)          # binary: many ties for the maximum
+    gg = rs.uniform(-1, 1, (B, H, W, 1)).astype(np.float32)
+    psfs = synth.make_psfs(L, K, kind)
+    O.PSFs_np = psfs
+    a = dev(p0).requires_grad_(True)
+    out = O.codePattern(a, dev(z), is_conv_psf=bool(conv), n_layers=L)
+    out.backward(dev(gg))
+    pc = t(np.repeat(p0, L, axis=-1)).requires_grad_(True)
+    ref = orc.codePattern(pc, t(z), psfs if conv else None, bool(conv))
+    ref.backward(t(gg))
+    bad = []
+    if DEBUG:
+        _, _, mx_, am_ = ops.CodePatternFn.apply(dev(p0), dev(z), O._device_psfs(a.device) if conv else None,
+                                                 O._layer_grid(L), bool(conv))
+        _, raw_, _ = orc.codePattern(t(np.repeat(p0, L, axis=-1)), t(z), psfs if conv else None, bool(conv), return_parts=True)
+        hw = orc.argmax_first_w_then_h(raw_.detach())
+        print("argmax lib", am_.cpu().numpy(), "oracle", (hw[:, 0] * W + hw[:, 1]).numpy(), "binary", bool(set(np.unique(p0)) <= {0.0, 1.0}))
+        d = np.abs(a.grad.cpu().numpy() - pc.grad[..., 0:1].numpy())[..., 0]
+        for b in range(B):
+            print(" b", b, "grad diff max", d[b].max(), "at", np.unravel_index(d[b].argmax(), d[b].shape), "n>1e-3", int((d[b] > 1e-3).sum()),
+                  "ref scale", float(pc.grad[b].abs().max()), "raw max", float(raw_[b].max()), "count of max", int((raw_[b] == raw_[b].max()).sum()))
+    e = rel_err(out.detach().cpu().numpy(), ref.detach().numpy())
+    if not e < TOL:
+        bad.append(("out", e))
+    # The gradient, image by image.  Where several pixels of the blurred image are equal up to the last bits
+    # (binary patterns under disc PSFs), which of them is "the" maximum is decided by the summation order of
+    # the convolution -- the library's and the host's differ -- and the share of the gradient that goes
+    # through the maximum lands on another pixel: such an image is compared only when both agree on the pixel.
+    _, raw, _ = orc.codePattern(pc.detach(), t(z), psfs if conv else None, bool(conv), return_parts=True)
+    hw = orc.argmax_first_w_then_h(raw)
+    am_ref = (hw[:, 0] * W + hw[:, 1]).numpy()
+    _, layer, mx, am = ops.CodePatternFn.apply(dev(p0), dev(z), O._device_psfs(a.device) if conv else None,
+                                               O._layer_grid(L), bool(conv))
+    am, mx = am.cpu().numpy().reshape(-1), mx.cpu().numpy().reshape(-1)
+    ga, gr = a.grad.cpu().numpy(), pc.grad[..., 0:1].numpy()
+    for b in range(B):
+        if am[b] != am_ref[b]:
+            top = float(raw[b].max())
+            if conv and abs(float(mx[b]) - top) <= 4e-7 * top and abs(float(raw[b].reshape(-1)[am[b]]) - top) <= 4e-7 * top:
+                continue                            # a tie up to rounding
+            bad.append(("argmax", (b, int(am[b]), int(am_ref[b]))))
+            continue
+        # on the scale of the upstream gradient too: at the maximum's pixel g/den and sum(g*out)/den cancel
+        gd = float(np.abs(ga[b] - gr[b]).max())
+        if not gd < TOL * max(float(np.abs(gr[b]).max()), float(np.abs(gg[b]).max())):
+            bad.append(("grad", b, gd))
+    got = layer.cpu().numpy().astype(np.int64)
+    got[got == 255] = -1
+    if not np.array_equal(got.reshape(B, H, W), orc.layer_index(t(z), L)[..., 0].numpy()):
+        bad.append(("layer", int((got.reshape(B, H, W) != orc.layer_index(t(z), L)[..., 0].numpy()).sum())))
+    return desc, bad
+
+
+def scatter64(g, grid, mask, H, W):
+    """d(sample * mask)/d(img) as a float64 scatter_add of the four weighted taps (stock tensor ops)."""
+    B = g.shape[0]
+    gx, gy = grid[..., 0], grid[..., 1]
+    x0, x1 = torch.floor(gx).clamp(0, W - 1), (torch.floor(gx) + 1).clamp(0, W - 1)
+    y0, y1 = torch.floor(gy).clamp(0, H - 1), (torch.floor(gy) + 1).clamp(0, H - 1)
+    wx0, wx1, wy0, wy1 = (x1 - gx).double(), (gx - x0).double(), (y1 - gy).double(), (gy - y0).double()
+    gm = (g[..., 0] * mask).double()
+    out = torch.zeros(B, H * W, dtype=torch.float64, device=g.device)
+    for xs, ys, w in ((x0, y0, wx0 * wy0), (x0, y1, wx0 * wy1), (x1, y0, wx1 * wy0), (x1, y1, wx1 * wy1)):
+        out.scatter_add_(1, (ys.long() * W + xs.long()).reshape(B, -1), (w * gm).reshape(B, -1))
+    return out.reshape(B, H, W, 1)
+
+
+def case_warp(rs, env):
+    G, synth, orc, ops = env["G"], env["synth"], env["orc"], env["ops"]
+    B = int(rs.randint(1, 4))
+    H, W = draw_size(rs)
+    if rs.uniform() < 0.2:
+        H, W = int(rs.randint(100, 420)), int(rs.randint(100, 700))
+    theta = float(rs.choice([0.0, 1.0, 3.0, 20.0]))
+    desc = dict(op="warp_p2c", B=B, H=H, W=W, theta=theta)
+    sc = synth.make_scene(B, H, W, int(rs.randint(1 << 30)), theta_deg=theta)
+    cx, cy = W / 2, H / 2
+
+    def get_intrinsic(Bn, device="cuda"):
+        K = np.diag([1666.67, 1666.67, 1, 1])
+        K[0][2], K[1][2] = cx, cy
+        return torch.from_numpy(K).float().to(device).unsqueeze(0).repeat(Bn, 1, 1)
+
+    old = G.get_intrinsic
+    G.get_intrinsic = get_intrinsic
+    try:
+        rays = G.pixel_to_ray_array(W, H)
+        z_p, z_c, pose = dev(sc["z_p"]), dev(sc["z_c"]), dev(sc["pose_p2c"])
+        coord_p = G.points_in_camera_coords(z_p, rays).permute(0, 3, 1, 2)
+        coord_c = G.points_in_camera_coords(z_c, rays).permute(0, 3, 1, 2)
+        img = rs.uniform(0, 1, (B, H, W, 1)).astype(np.float32)
+        gg = rs.uniform(-1, 1, (B, H, W, 1)).astype(np.float32)
+        ip = dev(img).requires_grad_(True)
+        Ic, gp2c, gc2p = G.warp_p2c(ip, coord_p, coord_c, pose)
+        Ic.backward(dev(gg))
+        mask = G.gen_visible_mask(gp2c, "all")
+    finally:
+        G.get_intrinsic = old
+    _, _, inv = ops.pose_transforms(pose, None, want_a=True)
+    ipr = t(img).requires_grad_(True)
+    cp, cc = orc.z2pointcloud(t(sc["z_p"])), orc.z2pointcloud(t(sc["z_c"]))
+    Ic_r, gp_r, gc_r = orc.warp_p2c(ipr, cp, cc, t(sc["pose_p2c"]), cx, cy, pose_c2p=inv.cpu())
+    Ic_r.backward(t(gg))
+    bad = []
+    if DEBUG:
+        a_, b_ = gp2c.cpu().numpy(), gp_r.numpy()
+        w = np.argwhere(a_ != b_)
+        print("grid_p2c mismatches", len(w))
+        for ix in w[:10]:
+            print(tuple(ix), repr(a_[tuple(ix)]), repr(b_[tuple(ix)]), a_[tuple(ix)].view(np.uint32) - b_[tuple(ix)].view(np.uint32))
+        a_, b_ = gc2p.cpu().numpy(), gc_r.detach().numpy()
+        w = np.argwhere(a_ != b_)
+        print("grid_c2p mismatches", len(w))
+        for ix in w[:10]:
+            print(tuple(ix), repr(a_[tuple(ix)]), repr(b_[tuple(ix)]))
+        d = np.abs(ip.grad.cpu().numpy() - ipr.grad.numpy())[..., 0]
+        print("grad diff max", d.max(), "at", np.unravel_index(d.argmax(), d.shape), "interior max",
+              d[:, 1:-1, 1:-1].max() if H > 2 and W > 2 else None, "scale", float(ipr.grad.abs().max()))
+    # Grids bit for bit -- except for one-row / one-column images: there torch's CPU matmul takes another
+    # route for the last (H*W mod 16) points (unfused products; seen as 1-ulp differences in exactly those
+    # elements), which is a property of the host library and not of the operator: 1e-6 of the scale then,
+    # and nothing downstream of a sample position that may have moved.
+    thin = H == 1 or W == 1
+    for name, a_, b_ in (("grid_p2c", gp2c.cpu().numpy(), gp_r.numpy()), ("grid_c2p", gc2p.cpu().numpy(), gc_r.detach().numpy())):
+        if thin:
+            if not rel_err(a_, b_) < 1e-6:
+                bad.append((name, rel_err(a_, b_)))
+        elif not np.array_equal(a_, b_):
+            bad.append((name, int((a_ != b_).sum())))
+    if thin:
+        return desc, bad
+    if not np.array_equal(mask.cpu().numpy(), orc.gen_visible_mask(gp_r, "all").numpy()):
+        bad.append(("mask", 0))
+    e = rel_err(Ic.detach().cpu().numpy(), Ic_r.detach().numpy())
+    if not e < TOL:
+        bad.append(("Ic", e))
+    # The gradient: the interior against the oracle; the whole image, border ring included, against the same
+    # scatter evaluated in float64.  A sample outside the image clamps both corners onto one border pixel
+    # with weights +w and -w as large as its distance to the image; the library adds nothing for it, the
+    # fp32 scatter-add of the reference leaves the rounding residue there (up to 0.1 at 20 degree poses).
+    ga, gr = ip.grad.cpu().numpy(), ipr.grad.numpy()
+    scale = max(float(np.abs(gr).max()), 1.0)
+    if H > 2 and W > 2:
+        gd = float(np.abs(ga - gr)[:, 1:-1, 1:-1].max())
+        if not gd < TOL * scale:
+            bad.append(("grad_Ip interior", gd))
+    ref64 = scatter64(dev(gg), gc2p, mask[..., 0], H, W)
+    gd = float((ip.grad.double() - ref64).abs().max())
+    if not gd < 1e-5 * scale:
+        bad.append(("grad_Ip vs float64", gd))
+    return desc, bad
+
+
+def case_capture(rs, env):
+    """The capture simulator's fused kernels against the operators they stand for, all on the GPU, bit for
+    bit: inverse warp straight from the depth maps (capture, camera-view scene coordinates, mask, grids),
+    the sensor model, and the shading folded into codePattern's forward (no blur and 3x3 / 5x5 / 7x7)."""
+    G, O, synth, ops, capture = env["G"], env["O"], env["synth"], env["ops"], env["capture"]
+    B = int(rs.randint(1, 4))
+    H, W = draw_size(rs)
+    theta = float(rs.choice([1.0, 3.0, 20.0]))
+    L = int(rs.choice([21, 41]))
+    desc = dict(op="capture", B=B, H=H, W=W, theta=theta, L=L)
+    sc = synth.make_scene(B, H, W, int(rs.randint(1 << 30)), theta_deg=theta)
+    cx, cy = W / 2, H / 2
+
+    def get_intrinsic(Bn, device="cuda"):
+        K = np.diag([1666.67, 1666.67, 1, 1])
+        K[0][2], K[1][2] = cx, cy
+        return torch.from_numpy(K).float().to(device).unsqueeze(0).repeat(Bn, 1, 1)
+
+    bad = []
+    old, keep = G.get_intrinsic, O.PSFs_np
+    G.get_intrinsic = get_intrinsic
+    try:
+        z_p, z_c, pose = dev(sc["z_p"]), dev(sc["z_c"]), dev(sc["pose_p2c"])
+        Ip = dev(rs.uniform(0, 1, (B, H, W, 1)).astype(np.float32))
+        shaded = ops.reflectance(Ip, z_p)
+        grid = O._layer_grid(L)
+        if not torch.equal(ops.code_pattern_shaded(Ip, z_p, grid), O.codePattern(shaded, z_p, is_conv_psf=False, n_layers=L)):
+            bad.append(("shaded no-blur", 0))
+        Kpsf = int(rs.choice([3, 5, 7]))
+        O.PSFs_np = synth.make_psfs(L, Kpsf, str(rs.choice(["disc", "gauss", "rand"])))
+        two = O.codePattern(shaded, z_p, is_conv_psf=True, n_layers=L)
+        if not torch.equal(ops.code_pattern_shaded(Ip, z_p, grid, O._device_psfs(z_p.device)), two):
+            bad.append(("shaded blur", Kpsf))
+        rays = G.pixel_to_ray_array(W, H)
+        coord_p = G.points_in_camera_coords(z_p, rays).permute(0, 3, 1, 2)
+        coord_c = G.points_in_camera_coords(z_c, rays).permute(0, 3, 1, 2)
+        Ic_ref, gp_ref, gc_ref = G.warp_p2c(Ip, coord_p, coord_c, pose)
+        vis_ref = G.gen_visible_mask(gp_ref, "all")
+        xy = capture._rays_xy(H, W, z_p.device).unsqueeze(0).expand(B, -1, -1, -1)
+        xyz_ref = G.bilinear_sampler(torch.cat([xy, z_p], dim=-1), gc_ref) * vis_ref
+        rx, ry = G._separable_rays(W, H, z_p.device)
+        off, sca = dev(rs.rand(B, 1, 1, 1).astype(np.float32)), dev(rs.rand(B, 1, 1, 1).astype(np.float32))
+        gau = dev(rs.randn(B, H, W, 1).astype(np.float32))
+        got = ops.capture_fwd(Ip, z_p, z_c, rx, ry, pose, G._intrinsics_for(B, z_p.device), off, gau, sca, want_grids=True)
+        for name, a_, b_ in (("Ic", got[0], Ic_ref), ("xyz", got[1], xyz_ref), ("grid_p2c", got[4], gp_ref), ("grid_c2p", got[5], gc_ref)):
+            if not torch.equal(a_, b_):
+                bad.append((name, int((a_ != b_).sum())))
+        Ie = Ic_ref.cpu() + off.cpu() * 0.05 + gau.cpu() * 0.005
+        Is = torch.clamp(Ie / Ie.amax(dim=(1, 2), keepdim=True) * (sca.cpu() * 0.3 + 0.7), 0.0, 1.0)
+        if not torch.equal(got[2].cpu(), Is):
+            bad.append(("sensor", int((got[2].cpu() != Is).sum())))
+        if not torch.equal(got[3].cpu(), (Is > 0.05).float() * vis_ref.cpu()):
+            bad.append(("valid", 0))
+    finally:
+        G.get_intrinsic, O.PSFs_np = old, keep
+    return desc, bad
+
+
+def environment():
+    import geometry_pytorch as G
+    import optics_pytorch as O
+    from fc3d import capture, ops, synth
+    import fc3d_oracle as orc
+    return dict(G=G, O=O, ops=ops, synth=synth, orc=orc, capture=capture)
+
+
+def sweep(cases, seed, env=None, verbose=False, only=None):
+    global DEBUG
+    DEBUG = DEBUG or bool(only)
+    env = env or environment()
+    rs = np.random.RandomState(seed)
+    failures = []
+    for i in range(cases):
+        fn = (case_code_pattern, case_code_pattern, case_warp, case_code_pattern, case_capture, case_warp)[i % 6]
+        sub = np.random.RandomState(int(rs.randint(1 << 30)))
+        if only and i not in only:
+            continue
+        desc, bad = fn(sub, env)
+        if verbose or bad:
+            print(i, desc, "FAIL %s" % bad if bad else "ok", flush=True)
+        if bad:
+            failures.append((i, desc, bad))
+    return failures
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=300)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("-v", action="store_true")
+    ap.add_argument("--only", type=int, nargs="*")
+    a = ap.parse_args()
+    DEBUG = bool(a.only)
+    f = sweep(a.cases, a.seed, verbose=a.v, only=a.only)
+    print("cases", a.cases, "failures", len(f))
+    sys.exit(1 if f else 0)
