@@ -274,12 +274,19 @@ __global__ __launch_bounds__(NT) void code_pattern_fwd_kernel(
     }
 }
 
+template <int AHEAD>
 __device__ __forceinline__ unsigned long long block_max_key(const unsigned long long* keys, int n,
                                                             unsigned long long* s_red) {
+    // AHEAD loads in flight per thread (indices past the end re-read the last key): one round trip per
+    // AHEAD x blockDim keys.  Pays where an image has thousands of keys; with a few hundred the extra loads
+    // cost more than the two round trips they save.
     unsigned long long k = 0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        unsigned long long v = keys[i];
-        k = v > k ? v : k;
+    for (int i = threadIdx.x; i < n; i += AHEAD * (int)blockDim.x) {
+        unsigned long long v[AHEAD];
+#pragma unroll
+        for (int j = 0; j < AHEAD; ++j) v[j] = keys[min(i + j * (int)blockDim.x, n - 1)];
+#pragma unroll
+        for (int j = 0; j < AHEAD; ++j) k = v[j] > k ? v[j] : k;
     }
     k = wave_max(k);
     if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = k;
@@ -289,9 +296,14 @@ __device__ __forceinline__ unsigned long long block_max_key(const unsigned long 
     return k;
 }
 
-constexpr int NORM_V = 4;   // float4s per thread of the normalisation pass
+// float4s per thread of the normalisation pass.  Every workgroup reduces all max keys of its image, so a
+// workgroup's share of the image has to outweigh them: 4 for ordinary images, 16 where an image has
+// thousands of keys (one per 16x16 tile of a 1024 x 1024 image: 32 KB of keys against 16 KB of pixels).
+constexpr int NORM_V_SMALL = 4;
+constexpr int NORM_V_LARGE = 16;
+constexpr int NORM_LARGE_KEYS = 2048;
 
-template <bool VEC>
+template <bool VEC, int NORM_V>
 __global__ __launch_bounds__(NT) void code_pattern_norm_kernel(
     const float* __restrict__ raw, const unsigned long long* __restrict__ tilekey, int ntiles, int H, int W,
     float* __restrict__ out, float* __restrict__ max_out, int* __restrict__ argmax_out) {
@@ -309,7 +321,7 @@ __global__ __launch_bounds__(NT) void code_pattern_norm_kernel(
             if (i < HW) v[j] = ld_pol<kNtNormLoad>(reinterpret_cast<const float4*>(raw + base + i));
         }
     }
-    const unsigned long long key = block_max_key(tilekey + (long)b * ntiles, ntiles, s_red);
+    const unsigned long long key = block_max_key<(NORM_V == NORM_V_LARGE ? 8 : 1)>(tilekey + (long)b * ntiles, ntiles, s_red);
     const float m = key_to_float((uint32_t)(key >> 32));
     const float den = m + 1e-10f;
     const float rden = 1.0f / den;      // one rounding more than raw / den: far inside the fp tolerance
@@ -1999,8 +2011,10 @@ extern "C" int fc3d_code_pattern_norm(void* stream, const float* raw, const uint
     if ((long)B * H * W >= (1L << 31) || B > 65535) return FC3D_ERANGE;
     const int ntiles = keys_per_image;
     const bool vec = (((long)H * W) % 4 == 0) && aligned16(raw) && aligned16(out);
-    dim3 g(cdiv((long)H * W, NT * 4 * NORM_V), B), blk(NT);
-    auto k = vec ? code_pattern_norm_kernel<true> : code_pattern_norm_kernel<false>;
+    const bool large = ntiles >= NORM_LARGE_KEYS;
+    dim3 g(cdiv((long)H * W, NT * 4 * (large ? NORM_V_LARGE : NORM_V_SMALL)), B), blk(NT);
+    auto k = vec ? (large ? code_pattern_norm_kernel<true, NORM_V_LARGE> : code_pattern_norm_kernel<true, NORM_V_SMALL>)
+                 : (large ? code_pattern_norm_kernel<false, NORM_V_LARGE> : code_pattern_norm_kernel<false, NORM_V_SMALL>);
     FC3D_LAUNCH("code_pattern_norm", k, g, blk, 0, (hipStream_t)stream, raw, (const unsigned long long*)tilekey_u64,
                 ntiles, H, W, out, max_out, argmax_i32);
     return FC3D_OK;
