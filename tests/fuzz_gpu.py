@@ -207,18 +207,24 @@ def case_warp(rs, env):
         d = np.abs(ip.grad.cpu().numpy() - ipr.grad.numpy())[..., 0]
         print("grad diff max", d.max(), "at", np.unravel_index(d.argmax(), d.shape), "interior max",
               d[:, 1:-1, 1:-1].max() if H > 2 and W > 2 else None, "scale", float(ipr.grad.abs().max()))
-    # Grids bit for bit -- except for one-row / one-column images: there torch's CPU matmul takes another
-    # route for the last (H*W mod 16) points (unfused products; seen as 1-ulp differences in exactly those
-    # elements), which is a property of the host library and not of the operator: 1e-6 of the scale then,
-    # and nothing downstream of a sample position that may have moved.
-    thin = H == 1 or W == 1
+    # Grids bit for bit.  One exception, a property of the host's matmul and not of the operator: torch's CPU product forms the last (H*W mod 16) points of an image without fused multiply-adds on
+    # some calls and with them on others (the same inputs give either, depending on where the buffers lie), so
+    # those points may differ from the library's fused chain in the last bits.  Accepted there and only there;
+    # nothing downstream of a sample position that may have moved is compared then.
+    P = H * W
+    tail_moved = False
     for name, a_, b_ in (("grid_p2c", gp2c.cpu().numpy(), gp_r.numpy()), ("grid_c2p", gc2p.cpu().numpy(), gc_r.detach().numpy())):
-        if thin:
-            if not rel_err(a_, b_) < 1e-6:
-                bad.append((name, rel_err(a_, b_)))
-        elif not np.array_equal(a_, b_):
-            bad.append((name, int((a_ != b_).sum())))
-    if thin:
+        if np.array_equal(a_, b_):
+            continue
+        a2, b2 = a_.reshape(B, P, 2), b_.reshape(B, P, 2)
+        px = np.argwhere((a2 != b2).any(axis=2))[:, 1]
+        # (a few ulps of the intermediate sums, whose size is the principal point's, not the result's)
+        off = float(np.abs(a2.astype(np.float64) - b2).max()) / max(1.0, float(np.abs(b2).max()), W / 2.0, H / 2.0)
+        if px.min() >= P - P % 16 and off <= 1e-6:
+            tail_moved = True
+        else:
+            bad.append((name, int((a_ != b_).sum()), off))
+    if tail_moved:
         return desc, bad
     if not np.array_equal(mask.cpu().numpy(), orc.gen_visible_mask(gp_r, "all").numpy()):
         bad.append(("mask", 0))
