@@ -13,6 +13,7 @@ of 4, 60 or 64, single rows and columns), a layer count, a PSF size (odd 1..33, 
   warp_p2c         both grids and the visibility mask bit for bit (the oracle is handed the library's
                    inverse pose); the capture and the gradient w.r.t. the sampled image to 1e-4
   capture kernels  the fused simulator kernels bit for bit against the operators composed on the GPU
+  re-projection    the one-kernel chain and the loss kernels against the composed operators
 
 The bars are the ones of tests/test_gpu_parity.py."""
 import argparse
@@ -306,6 +307,58 @@ def case_capture(rs, env):
     return desc, bad
 
 
+def case_reproject(rs, env):
+    """The one-kernel re-projection chain and the loss kernels on top of it against the same chain composed
+    from the drop-in operators and tensor reductions, all on the GPU: forward values of the chain bit for bit,
+    d/d(depth) to 1e-4 of the scale, the four losses to 2e-5 and their gradient to 1e-4; whole images and
+    centre crops."""
+    G, O, synth, capture = env["G"], env["O"], env["synth"], env["capture"]
+    B = int(rs.randint(1, 4))
+    H, W = int(rs.randint(24, 140)), int(rs.randint(24, 200))
+    N = None if rs.uniform() < 0.4 else int(rs.randint(12, min(H, W) + 1))
+    theta = float(rs.choice([1.0, 3.0]))
+    desc = dict(op="reproject", B=B, H=H, W=W, crop=N, theta=theta)
+    sc = synth.make_scene(B, H, W, int(rs.randint(1 << 30)), theta_deg=theta)
+    bad = []
+    keep = O.PSFs_np
+    O.PSFs_np = synth.make_psfs(21, 5, "disc")
+    try:
+        pat = dev(rs.uniform(0.5, 1.0, (1, H, W, 1)).astype(np.float32))
+        with torch.no_grad():
+            out = capture.forward_model(dev(sc["z_p"]), dev(sc["z_c"]), dev(sc["pose_p2c"]), 21, True, N, pattern=pat,
+                                        intrinsics=(W / 2, H / 2))
+        Ic_s, Ic_m, xyz, xy, zc, zp, pose, _, Ic, Ip_coded, _ = out
+        z0 = xyz[..., 2:3] + 0.003 * dev(rs.randn(*zc.shape).astype(np.float32))
+        g_ic, g_zc = dev(rs.uniform(-1, 1, zc.shape).astype(np.float32)), dev(rs.uniform(-1, 1, zc.shape).astype(np.float32))
+        res = {}
+        for fused in (True, False):
+            zh = z0.clone().requires_grad_(True)
+            zc_r, Ic_r = capture.reproject(zh, pose, xy, Ip_coded, fused=fused, intrinsics=(W / 2, H / 2))
+            ((Ic_r * g_ic).sum() + (zc_r * g_zc).sum()).backward()
+            res[fused] = (zc_r.detach(), Ic_r.detach(), zh.grad.clone())
+        if not (torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])):
+            bad.append(("chain forward", int((res[True][1] != res[False][1]).sum())))
+        gd = float((res[True][2] - res[False][2]).abs().max())
+        if not gd <= TOL * max(float(res[False][2].abs().max()), 1e-30):
+            bad.append(("chain grad", gd))
+        if float(capture.erode(Ic_m, 5).mean()) > 0.05:           # else the masked means are 0 / 0
+            res = {}
+            for fused in (True, False):
+                zh = z0.clone().requires_grad_(True)
+                vals = capture.reProj_IpGT(zh, pose, xy, Ic, zc, Ic_m, Ip_coded, fused=fused, intrinsics=(W / 2, H / 2))
+                (vals[0] + 0.5 * vals[2]).backward()
+                res[fused] = ([float(v) for v in vals], zh.grad.clone())
+            for a_, b_ in zip(res[True][0], res[False][0]):
+                if not abs(a_ - b_) <= 2e-5 * abs(b_):
+                    bad.append(("loss", a_, b_))
+            gd = float((res[True][1] - res[False][1]).abs().max())
+            if not gd <= TOL * float(res[False][1].abs().max()):
+                bad.append(("loss grad", gd))
+    finally:
+        O.PSFs_np = keep
+    return desc, bad
+
+
 def environment():
     import geometry_pytorch as G
     import optics_pytorch as O
@@ -321,7 +374,8 @@ def sweep(cases, seed, env=None, verbose=False, only=None):
     rs = np.random.RandomState(seed)
     failures = []
     for i in range(cases):
-        fn = (case_code_pattern, case_code_pattern, case_warp, case_code_pattern, case_capture, case_warp)[i % 6]
+        fn = (case_code_pattern, case_code_pattern, case_warp, case_code_pattern, case_capture, case_warp,
+              case_code_pattern, case_reproject)[i % 8]
         sub = np.random.RandomState(int(rs.randint(1 << 30)))
         if only and i not in only:
             continue
