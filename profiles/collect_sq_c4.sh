@@ -1,6 +1,7 @@
 #!/bin/bash
-# usage: profiles/collect_sq_c4.sh tag   -- two SQ counter passes (8 counters each) over bench.py --workload C4; summary in gpurun_out/<tag>_sq.txt
+# usage: profiles/collect_sq_c4.sh tag [workload]  -- two SQ counter passes (8 counters each) over bench.py --workload C4 (or the one named); summary in gpurun_out/<tag>_sq.txt
 tag=$1
+wl=${2:-C4}
 root=$PWD
 
 cd /tmp && export TMPDIR=/tmp && cd "$root" || exit 1
@@ -9,7 +10,7 @@ p2="SQ_INST_CYCLES_SMEM SQ_IFETCH SQ_INSTS_VALU SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD
 i=1
 for p in "$p1" "$p2"; do
   rm -rf gpurun_out/${tag}_sq$i
-  timeout -s KILL 150 rocprofv3 --pmc $p --output-format csv -d gpurun_out/${tag}_sq$i -- python3 bench.py --workload C4 --launch eager --no-cpu-baseline --steps 3 --warmup 1 > gpurun_out/${tag}_sq$i.log 2>&1 || { echo "pass $i failed"; tail -5 gpurun_out/${tag}_sq$i.log; exit 1; }
+  timeout -s KILL 150 rocprofv3 --pmc $p --output-format csv -d gpurun_out/${tag}_sq$i -- python3 bench.py --workload $wl --launch eager --no-cpu-baseline --steps 3 --warmup 1 > gpurun_out/${tag}_sq$i.log 2>&1 || { echo "pass $i failed"; tail -5 gpurun_out/${tag}_sq$i.log; exit 1; }
   echo "pass $i ok"
   i=$((i+1))
 done

@@ -9,7 +9,7 @@ for d in sys.argv[1:]:
             rows[k][c].append(v)
 names = sorted({c for k in rows for c in rows[k]})
 for k in rows:
-    if "sweep" not in k and "gather" not in k and "roll" not in k: continue
+    if not any(t in k for t in ("sweep", "gather", "roll", "warp_sample", "project_kernel", "norm_kernel")): continue
     print(k[:70])
     for c in names:
         v = rows[k].get(c)
