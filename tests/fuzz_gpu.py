@@ -14,6 +14,8 @@ of 4, 60 or 64, single rows and columns), a layer count, a PSF size (odd 1..33, 
                    inverse pose); the capture and the gradient w.r.t. the sampled image to 1e-4
   capture kernels  the fused simulator kernels bit for bit against the operators composed on the GPU
   re-projection    the one-kernel chain and the loss kernels against the composed operators
+  image gradient   the gather form and the atomic form of the sampler's image gradient against a float64 scatter,
+                   for smooth, magnifying, shrinking, discontinuous and random sampling grids
 
 The bars are the ones of tests/test_gpu_parity.py."""
 import argparse
@@ -359,6 +361,94 @@ def case_reproject(rs, env):
     return desc, bad
 
 
+def case_gather(rs, env):
+    """d out / d img of the one-channel sampler for grids of every kind -- smooth, magnifying, shrinking (many
+    samples per source cell), discontinuous, pure noise -- with masks, NaN / infinite / exact-integer coordinates,
+    source and target images of different sizes: the gather form (twice: same bits) and the atomic form against
+    a float64 scatter_add of the four weighted taps."""
+    ops = env["ops"]
+    B = int(rs.randint(1, 4))
+    Hs, Ws = draw_size(rs)
+    if rs.uniform() < 0.5:
+        Ht, Wt = Hs, Ws
+    else:
+        Ht, Wt = draw_size(rs)
+    if rs.uniform() < 0.15:                          # targets of several index scan rounds
+        Ht, Wt = int(rs.randint(300, 800)), int(rs.randint(600, 1100))
+    kind = str(rs.choice(["smooth", "random", "zoom", "jump", "shrink"]))
+    desc = dict(op="gather", B=B, Hs=Hs, Ws=Ws, Ht=Ht, Wt=Wt, kind=kind)
+    ys, xs = np.meshgrid(np.arange(Ht), np.arange(Wt), indexing="ij")
+    if kind == "random":
+        gx, gy = rs.uniform(-3, Ws + 3, (B, Ht, Wt)), rs.uniform(-3, Hs + 3, (B, Ht, Wt))
+    else:
+        sx, sy = (Ws - 1) / max(Wt - 1, 1), (Hs - 1) / max(Ht - 1, 1)
+        if kind == "zoom":
+            sx, sy = sx * 0.3, sy * 0.3
+        if kind == "shrink":
+            sx, sy = sx * 1.7, sy * 1.7
+        th = rs.uniform(-0.2, 0.2)
+        gx = (np.cos(th) * xs * sx - np.sin(th) * ys * sy + rs.uniform(-3, 3))[None] + rs.uniform(-0.4, 0.4, (B, Ht, Wt))
+        gy = (np.sin(th) * xs * sx + np.cos(th) * ys * sy + rs.uniform(-3, 3))[None] + rs.uniform(-0.4, 0.4, (B, Ht, Wt))
+        if kind == "jump":
+            gx[:, :, Wt // 2:] += rs.uniform(5, 60)
+            gy[:, Ht // 3:, :] -= rs.uniform(2, 20)
+    grid = np.stack([gx, gy], -1).astype(np.float32)
+    n_odd = min(grid.size // 8, 6)
+    for _ in range(n_odd):                           # hostile coordinates at random places
+        b, y, x = int(rs.randint(B)), int(rs.randint(Ht)), int(rs.randint(Wt))
+        grid[b, y, x] = [(np.nan, 1.0), (1e9, -1e9), (float(Ws - 1), float(Hs - 1)), (np.inf, 0.5), (0.0, 0.0),
+                         (-0.0, float(Hs))][int(rs.randint(6))]
+    g = rs.uniform(-1, 1, (B, Ht, Wt, 1)).astype(np.float32)
+    mask = (rs.uniform(0, 1, (B, Ht, Wt)) > rs.choice([0.0, 0.2, 0.9])).astype(np.uint8)
+    gd, gg, gm = dev(grid), dev(g), dev(mask)
+
+    def reference(use_mask):
+        x, y = gd[..., 0], gd[..., 1]
+        fx, fy = torch.floor(x), torch.floor(y)
+        x0, x1 = fx.clamp(0, Ws - 1), (fx + 1).clamp(0, Ws - 1)
+        y0, y1 = fy.clamp(0, Hs - 1), (fy + 1).clamp(0, Hs - 1)
+        live = (x0 != x1) & (y0 != y1) & ~torch.isnan(x) & ~torch.isnan(y)
+        if use_mask:
+            live = live & (gm != 0)
+        v = torch.where(live, gg[..., 0], torch.zeros_like(x)).double()
+        wx0, wx1, wy0, wy1 = (x1 - x).double(), (x - x0).double(), (y1 - y).double(), (y - y0).double()
+        out = torch.zeros(B, Hs * Ws, dtype=torch.float64, device="cuda")
+        mag = torch.zeros_like(out)                  # sum of |terms| per cell: what fp32 summation noise scales with
+        for xa, ya, w in ((x0, y0, wx0 * wy0), (x0, y1, wx0 * wy1), (x1, y0, wx1 * wy0), (x1, y1, wx1 * wy1)):
+            w = torch.where(live, w, torch.zeros_like(w))
+            idx = (torch.nan_to_num(ya) * Ws + torch.nan_to_num(xa)).long().reshape(B, -1)
+            out.scatter_add_(1, idx, (w * v).reshape(B, -1))
+            mag.scatter_add_(1, idx, (w * v).abs().reshape(B, -1))
+        return out.reshape(B, Hs, Ws, 1), float(mag.max())
+
+    bad = []
+    old = ops.set_image_gradient_mode("ordered")
+    try:
+        for use_mask in (False, True):
+            m = gm if use_mask else None
+            # the bar is relative to the largest sum of |terms| that meets in one cell: equal to the result's
+            # scale for ordinary warps, far above it when 10^5 samples of both signs are squeezed onto one cell
+            ref, mag = reference(use_mask)
+            scale = max(float(ref.abs().max()), mag, 1e-30)
+            got = ops._bilinear_bwd_img(gg, gd, m, B, Hs, Ws, 1, Ht, Wt)
+            e = float((got.double() - ref).abs().max())
+            if DEBUG:
+                print("ordered err", e, "max|ref|", float(ref.abs().max()), "max sum|terms|", mag, "ratio", e / max(mag, 1e-30))
+            if not e <= 2e-6 * scale:
+                bad.append(("ordered", use_mask, e, scale))
+            if not torch.equal(got, ops._bilinear_bwd_img(gg, gd, m, B, Hs, Ws, 1, Ht, Wt)):
+                bad.append(("ordered twice", use_mask))
+            ops.set_image_gradient_mode("atomic")
+            atom = ops._bilinear_bwd_img(gg, gd, m, B, Hs, Ws, 1, Ht, Wt)
+            ops.set_image_gradient_mode("ordered")
+            e = float((atom.double() - ref).abs().max())
+            if not e <= 2e-6 * scale:
+                bad.append(("atomic", use_mask, e, scale))
+    finally:
+        ops.set_image_gradient_mode(old)
+    return desc, bad
+
+
 def environment():
     import geometry_pytorch as G
     import optics_pytorch as O
@@ -375,7 +465,7 @@ def sweep(cases, seed, env=None, verbose=False, only=None):
     failures = []
     for i in range(cases):
         fn = (case_code_pattern, case_code_pattern, case_warp, case_code_pattern, case_capture, case_warp,
-              case_code_pattern, case_reproject)[i % 8]
+              case_gather, case_reproject)[i % 8]
         sub = np.random.RandomState(int(rs.randint(1 << 30)))
         if only and i not in only:
             continue
