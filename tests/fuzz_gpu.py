@@ -14,6 +14,8 @@ of 4, 60 or 64, single rows and columns), a layer count, a PSF size (odd 1..33, 
                    inverse pose); the capture and the gradient w.r.t. the sampled image to 1e-4
   capture kernels  the fused simulator kernels bit for bit against the operators composed on the GPU
   re-projection    the one-kernel chain and the loss kernels against the composed operators
+  operators        bilinear_sampler (1-4 channels, both gradients) and coord_transform (arbitrary matrices, both
+                   gradients) against the oracle's autograd
   image gradient   the gather form and the atomic form of the sampler's image gradient against a float64 scatter,
                    for smooth, magnifying, shrinking, discontinuous and random sampling grids
 
@@ -449,6 +451,72 @@ def case_gather(rs, env):
     return desc, bad
 
 
+def case_operators(rs, env):
+    """The stand-alone operators with their gradients against the oracle's autograd: bilinear_sampler on images
+    of one to four channels (output bit for bit -- both are handed the same coordinates --, image gradient and
+    coordinate gradient to 1e-4 of the scale) and coord_transform with arbitrary 4x4 matrices (grid to 1e-6:
+    the host product's last points, see case_warp; point and matrix gradients to 1e-4)."""
+    G, orc = env["G"], env["orc"]
+    B = int(rs.randint(1, 4))
+    Hs, Ws = draw_size(rs)
+    Ht, Wt = (Hs, Ws) if rs.uniform() < 0.5 else draw_size(rs)
+    C = int(rs.choice([1, 1, 2, 3, 4]))
+    desc = dict(op="operators", B=B, Hs=Hs, Ws=Ws, Ht=Ht, Wt=Wt, C=C)
+    bad = []
+    # --- sampler: coordinates inside the image by more than the reference's own border effects, plus a few outside
+    ys, xs = np.meshgrid(np.arange(Ht), np.arange(Wt), indexing="ij")
+    sx, sy = (Ws - 1) / max(Wt - 1, 1), (Hs - 1) / max(Ht - 1, 1)
+    gx = (xs * sx)[None] + rs.uniform(-0.45, 0.45, (B, Ht, Wt)) + rs.uniform(-2, 2)
+    gy = (ys * sy)[None] + rs.uniform(-0.45, 0.45, (B, Ht, Wt)) + rs.uniform(-2, 2)
+    co_np = np.stack([gx, gy], -1).astype(np.float32)
+    # keep samples off integer coordinates: there d/d(coordinate) jumps and a last-bit difference picks a side
+    frac = co_np - np.floor(co_np)
+    co_np = np.where((frac < 0.02) | (frac > 0.98), np.floor(co_np) + 0.5, co_np).astype(np.float32)
+    img_np = rs.uniform(0, 1, (B, Hs, Ws, C)).astype(np.float32)
+    g_np = rs.uniform(-1, 1, (B, Ht, Wt, C)).astype(np.float32)
+    img, co = dev(img_np).requires_grad_(True), dev(co_np).requires_grad_(True)
+    out = G.bilinear_sampler(img, co)
+    out.backward(dev(g_np))
+    img_r, co_r = t(img_np).requires_grad_(True), t(co_np).requires_grad_(True)
+    out_r = orc.bilinear_sampler(img_r, co_r)
+    out_r.backward(t(g_np))
+    if not np.array_equal(out.detach().cpu().numpy(), out_r.detach().numpy()):
+        bad.append(("sampler out", int((out.detach().cpu().numpy() != out_r.detach().numpy()).sum())))
+    gi, gi_r = img.grad.cpu().numpy(), img_r.grad.numpy()
+    inner = (slice(None), slice(1, -1), slice(1, -1)) if Hs > 2 and Ws > 2 else None     # border ring: see case_warp
+    if inner is not None:
+        e = float(np.abs(gi - gi_r)[inner].max()) if gi[inner].size else 0.0
+        if not e <= TOL * max(float(np.abs(gi_r).max()), 1.0):
+            bad.append(("sampler grad img", e))
+    e = float(np.abs(co.grad.cpu().numpy() - co_r.grad.numpy()).max())
+    if not e <= TOL * max(float(co_r.grad.abs().max()), 1e-30):
+        bad.append(("sampler grad coords", e, float(co_r.grad.abs().max())))
+    # --- projection with an arbitrary matrix
+    H, W = Ht, Wt
+    pts = np.concatenate([rs.uniform(-0.3, 0.3, (B, 2, H, W)), rs.uniform(0.6, 1.0, (B, 1, H, W)), np.ones((B, 1, H, W))], 1).astype(np.float32)
+    tr = (np.diag([1500.0, 1500.0, 1.0, 1.0])[None] + rs.uniform(-0.05, 0.05, (B, 4, 4)) * np.array([300.0, 300.0, 1.0, 1.0])[None, :, None])
+    tr[:, 0, 2] += W / 2
+    tr[:, 1, 2] += H / 2
+    tr = tr.astype(np.float32)
+    gg = rs.uniform(-1, 1, (B, H, W, 2)).astype(np.float32)
+    c, m = dev(pts).requires_grad_(True), dev(tr).requires_grad_(True)
+    grid = G.coord_transform(c, m)
+    grid.backward(dev(gg))
+    c_r, m_r = t(pts).requires_grad_(True), t(tr).requires_grad_(True)
+    grid_r = orc.coord_transform(c_r, m_r)
+    grid_r.backward(t(gg))
+    if not rel_err(grid.detach().cpu().numpy(), grid_r.detach().numpy()) < 1e-6:
+        bad.append(("project grid", rel_err(grid.detach().cpu().numpy(), grid_r.detach().numpy())))
+    e = rel_err(c.grad.cpu().numpy(), c_r.grad.numpy())
+    if not e < TOL:
+        bad.append(("project grad points", e))
+    # a matrix entry is a sum over all pixels of terms of both signs
+    e = float(np.abs(m.grad.cpu().numpy() - m_r.grad.numpy()).max()) / max(float(m_r.grad.abs().max()), 1e-30)
+    if not e < 10 * TOL:
+        bad.append(("project grad matrix", e))
+    return desc, bad
+
+
 def environment():
     import geometry_pytorch as G
     import optics_pytorch as O
@@ -465,7 +533,7 @@ def sweep(cases, seed, env=None, verbose=False, only=None):
     failures = []
     for i in range(cases):
         fn = (case_code_pattern, case_code_pattern, case_warp, case_code_pattern, case_capture, case_warp,
-              case_gather, case_reproject)[i % 8]
+              case_gather, case_reproject, case_operators)[i % 9]
         sub = np.random.RandomState(int(rs.randint(1 << 30)))
         if only and i not in only:
             continue
