@@ -98,20 +98,37 @@ def case_code_pattern(rs, env):
     gg = rs.uniform(-1, 1, (B, H, W, 1)).astype(np.float32)
     psfs = synth.make_psfs(L, K, kind)
     O.PSFs_np = psfs
-    a = dev(p0).requires_grad_(True)
-    out = O.codePattern(a, dev(z), is_conv_psf=bool(conv), n_layers=L)
+    form = int(rs.randint(3))       # the pattern as one channel, as channel 0 of L stored channels, as an expanded view
+    desc["form"] = form
+    if form == 1:
+        full = rs.uniform(0, 1, (B, H, W, L)).astype(np.float32)
+        full[..., 0:1] = p0
+        a = dev(full).requires_grad_(True)
+        out = O.codePattern(a, dev(z), is_conv_psf=bool(conv))
+    elif form == 2:
+        a = dev(p0).requires_grad_(True)
+        out = O.codePattern(a.expand(-1, -1, -1, L), dev(z), is_conv_psf=bool(conv))
+    else:
+        a = dev(p0).requires_grad_(True)
+        out = O.codePattern(a, dev(z), is_conv_psf=bool(conv), n_layers=L)
     out.backward(dev(gg))
+    if form == 1:
+        a_grad = a.grad[..., 0:1]
+    else:
+        a_grad = a.grad
     pc = t(np.repeat(p0, L, axis=-1)).requires_grad_(True)
     ref = orc.codePattern(pc, t(z), psfs if conv else None, bool(conv))
     ref.backward(t(gg))
     bad = []
+    if form == 1 and float(a.grad[..., 1:].abs().max()) != 0.0:
+        bad.append(("other channels' gradient", float(a.grad[..., 1:].abs().max())))
     if DEBUG:
         _, _, mx_, am_ = ops.CodePatternFn.apply(dev(p0), dev(z), O._device_psfs(a.device) if conv else None,
                                                  O._layer_grid(L), bool(conv))
         _, raw_, _ = orc.codePattern(t(np.repeat(p0, L, axis=-1)), t(z), psfs if conv else None, bool(conv), return_parts=True)
         hw = orc.argmax_first_w_then_h(raw_.detach())
         print("argmax lib", am_.cpu().numpy(), "oracle", (hw[:, 0] * W + hw[:, 1]).numpy(), "binary", bool(set(np.unique(p0)) <= {0.0, 1.0}))
-        d = np.abs(a.grad.cpu().numpy() - pc.grad[..., 0:1].numpy())[..., 0]
+        d = np.abs(a_grad.cpu().numpy() - pc.grad[..., 0:1].numpy())[..., 0]
         for b in range(B):
             print(" b", b, "grad diff max", d[b].max(), "at", np.unravel_index(d[b].argmax(), d[b].shape), "n>1e-3", int((d[b] > 1e-3).sum()),
                   "ref scale", float(pc.grad[b].abs().max()), "raw max", float(raw_[b].max()), "count of max", int((raw_[b] == raw_[b].max()).sum()))
@@ -128,7 +145,7 @@ def case_code_pattern(rs, env):
     _, layer, mx, am = ops.CodePatternFn.apply(dev(p0), dev(z), O._device_psfs(a.device) if conv else None,
                                                O._layer_grid(L), bool(conv))
     am, mx = am.cpu().numpy().reshape(-1), mx.cpu().numpy().reshape(-1)
-    ga, gr = a.grad.cpu().numpy(), pc.grad[..., 0:1].numpy()
+    ga, gr = a_grad.cpu().numpy(), pc.grad[..., 0:1].numpy()
     for b in range(B):
         if am[b] != am_ref[b]:
             top = float(raw[b].max())
@@ -184,6 +201,18 @@ def case_warp(rs, env):
         z_p, z_c, pose = dev(sc["z_p"]), dev(sc["z_c"]), dev(sc["pose_p2c"])
         coord_p = G.points_in_camera_coords(z_p, rays).permute(0, 3, 1, 2)
         coord_c = G.points_in_camera_coords(z_c, rays).permute(0, 3, 1, 2)
+        layout = int(rs.randint(4))     # as made (depth plane read), a copy of the view, planar, rows with a gap
+        desc["layout"] = layout
+        if layout == 1:
+            coord_p, coord_c = coord_p.clone(memory_format=torch.preserve_format), coord_c.clone(memory_format=torch.preserve_format)
+        elif layout == 2:
+            coord_p, coord_c = coord_p.contiguous(), coord_c.contiguous()
+        elif layout == 3:
+            def gap(c):
+                wide = torch.empty(B, 4, H, W + 3, device="cuda")[..., 1:-2]
+                wide.copy_(c)
+                return wide
+            coord_p, coord_c = gap(coord_p), gap(coord_c)
         img = rs.uniform(0, 1, (B, H, W, 1)).astype(np.float32)
         gg = rs.uniform(-1, 1, (B, H, W, 1)).astype(np.float32)
         ip = dev(img).requires_grad_(True)
