@@ -19,7 +19,7 @@ class LayerGrid(ctypes.Structure):
                 ("n_layers", c_int32)]
 
 
-ABI_VERSION = 211  # FC3D_VERSION of include/fc3d.h this binding was written against (a stale library is refused)
+ABI_VERSION = 212  # FC3D_VERSION of include/fc3d.h this binding was written against (a stale library is refused)
 
 P = c_void_p      # device pointers travel as integers
 I64 = c_int64
@@ -40,7 +40,7 @@ SIGNATURES = {
     "fc3d_code_pattern_bwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
     "fc3d_code_pattern_bwd_dot_supported": (c_int, [c_int, c_int, c_int]),
     "fc3d_code_pattern_bwd_dot": (c_int, [P, P, P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
-    "fc3d_bilinear_bwd_img_dot_count": (c_int, [c_int, c_int]),
+    "fc3d_bilinear_bwd_img_dot_count": (c_int, [c_int, c_int, c_int]),
     "fc3d_bilinear_bwd_img_dot": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P]),
     "fc3d_pose_transforms": (c_int, [P, P, P, I64, c_int, P, P, P, P, c_size_t]),
     "fc3d_project_fwd": (c_int, [P, P, I64, I64, I64, I64, P, c_int, c_int, c_int, P]),

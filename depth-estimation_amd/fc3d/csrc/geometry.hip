@@ -578,11 +578,25 @@ __global__ __launch_bounds__(NT) void bilinear_tap_index_kernel(const float* __r
 #define FC3D_GDBG 0          // timing experiments only: 1 no window adds, 2 no sampling at all, 4 no run / segment scans, 8 no election, 16 one election round
 #endif
 #ifndef FC3D_GATHER_GY
-#define FC3D_GATHER_GY 12
+#define FC3D_GATHER_GY 0     // 0: the tile height is chosen per launch (gather_tile_rows); otherwise fixed (experiments)
 #endif
-constexpr int GX = 64, GY = FC3D_GATHER_GY;   // source tile of one wavefront
+constexpr int GX = 64;                        // source tile of one wavefront: GX columns x GY rows (GY a template parameter)
 constexpr int GWS = GX + 8;                   // window row stride: tile column 0 at window column 4 (16-byte aligned rows)
-constexpr int GWR = GY + 2;                   // window rows: tile row 0 at window row 1
+// window rows: tile row 0 at window row 1
+constexpr int gather_window_rows(int gy) { return gy + 2; }
+// Tile height of a launch.  Twelve rows are the optimum when the grid fills the chip several times over (fewer
+// rows: more index scanning per sample; more: more candidates per tile).  A small problem -- one 256 x 256
+// image is 22 workgroups of twelve-row tiles -- is bound by the length of one wavefront's chain of scans and
+// sample steps instead, which shorter tiles cut: the tallest of 12 / 6 / 4 rows that still gives 1,024
+// workgroups, else 4 (measured at 1 ... 64 images of 256^2 and 1 ... 8 of 512^2: 19.7 -> 13.7 us for one
+// 256^2 image, break-even at about two million pixels).
+static int gather_tile_rows(int B, int Hs, int Ws) {
+    if (FC3D_GATHER_GY) return FC3D_GATHER_GY;
+    const long cols = (Ws + (NT / 64) * GX - 1) / ((NT / 64) * GX);
+    if ((long)B * cols * ((Hs + 11) / 12) >= 1024) return 12;
+    if ((long)B * cols * ((Hs + 5) / 6) >= 1024) return 6;
+    return 4;
+}
 constexpr int G_GROUPS = NT * 2;              // group boxes the workgroup scans per round
 constexpr int G_HITCAP = 2 * G_GROUPS / (NT / 64);   // group hits a scanning wavefront can hold: two rounds' worth
 constexpr int G_UNROLL = 2;                   // run-level steps (64 boxes each) whose loads are in flight together
@@ -610,7 +624,7 @@ __device__ __forceinline__ int list_append(L list, int n, bool hit, V value, int
     return n + __popcll(bal);
 }
 
-constexpr int G_WIN = GWR * GWS;                 // window cells
+constexpr int gather_window_cells(int gy) { return gather_window_rows(gy) * GWS; }
 // window_add4 with the election slots shared by all cells that agree in the low bits of their
 // index: two lanes with different cells may now meet in a slot, in which case one of them simply
 // waits a turn.
@@ -650,12 +664,13 @@ __device__ __forceinline__ void window_add4_hashed(lds_vfloat win, lds_vu8 own, 
 struct GatherTile {
     float cx, cy;                     // centre of the base cells whose taps reach the tile (GX + 1 columns, GY + 1 rows of them)
 };
-static_assert(GX % 2 == 0 && GY % 2 == 0, "the base cells of a tile need a centre cell");
-constexpr int G_CENTRE = (GY / 2) * GWS + GX / 2 + 3;   // its window cell: tile row 0 is window row 1, tile column 0 window column 4
+static_assert(GX % 2 == 0, "the base cells of a tile need a centre cell");
+// its window cell: tile row 0 is window row 1, tile column 0 window column 4
+constexpr int gather_centre_cell(int gy) { return (gy / 2) * GWS + GX / 2 + 3; }
 #ifndef FC3D_GATHER_PIPE
 #define FC3D_GATHER_PIPE 0        // 1: two batches of sample loads in flight, the second issued before the first batch is added (measured slower: 46.6-53 against 45.5 us, registers)
 #endif
-template <bool PAIRS>
+template <bool PAIRS, int GY>
 __device__ __noinline__ void gather_drain(const float2* __restrict__ gb, const float* __restrict__ vb, unsigned HWt,
                                           lds_vfloat win, lds_vu8 own, lds_vint cand, lds_vint cbits, int n,
                                           GatherTile tl) {
@@ -663,7 +678,8 @@ __device__ __noinline__ void gather_drain(const float2* __restrict__ gb, const f
     const int lane = threadIdx.x & 63;
     const auto gbu = uniform_global(gb);
     const auto vbu = uniform_global(vb);
-    lds_vfloat winc = win + G_CENTRE;
+    static_assert(GY % 2 == 0, "the base cells of a tile need a centre cell");
+    lds_vfloat winc = win + gather_centre_cell(GY);
     // the loads of one batch: G_DEPTH steps of STEP segments each
     auto issue = [&](GatherSample (&sm)[G_DEPTH], int e0) {
         if constexpr (PAIRS) {
@@ -753,11 +769,12 @@ __device__ __noinline__ void gather_drain(const float2* __restrict__ gb, const f
 #ifdef FC3D_GATHER_WAVES
 __attribute__((amdgpu_waves_per_eu(FC3D_GATHER_WAVES, FC3D_GATHER_WAVES)))
 #endif
-template <bool PAIRS>
+template <bool PAIRS, int GY>
 __global__ __launch_bounds__(NT) void bilinear_bwd_img_gather_kernel(
     const float* __restrict__ g_out, const float* __restrict__ grid, void* __restrict__ tap_index, int B, int groups,
     int Hs, int Ws, unsigned HWt, float* __restrict__ g_img, const float* __restrict__ img,
     float* __restrict__ dot_partial) {
+    constexpr int GWR = gather_window_rows(GY), G_WIN = gather_window_cells(GY);
     __shared__ __align__(16) float s_win[NT / 64][G_WIN];
     __shared__ uint8_t s_own[NT / 64][G_OWN];
     __shared__ uint16_t s_ghit[NT / 64][G_HITCAP];          // groups that meet the workgroup's row of tiles, per scanning wavefront, counted from `cbase`
@@ -789,7 +806,7 @@ __global__ __launch_bounds__(NT) void bilinear_bwd_img_gather_kernel(
     // hands the first m candidates to gather_drain and moves the rest (fewer than 64) to the front
     auto drain_front = [&](int& ncand, int m) {
 #if !(FC3D_GDBG & 2)
-        if (m > 0) gather_drain<PAIRS>(gb, vb, HWt, win, own, cand, cbits, m, tl);
+        if (m > 0) gather_drain<PAIRS, GY>(gb, vb, HWt, win, own, cand, cbits, m, tl);
 #endif
         const int rest = ncand - m;
         int keep_s = 0, keep_b = 0;
@@ -1644,16 +1661,24 @@ extern "C" int fc3d_bilinear_tap_index(void* stream, const float* grid, const ui
 static int launch_gather(hipStream_t s, const float* g_out, const float* grid, void* index, int B, int Hs, int Ws, int Ht,
                          int Wt, float* g_img, const float* img, float* dot_partial) {
     const long HWt = (long)Ht * Wt;
-    const dim3 gridDim3(cdiv(Ws, (NT / 64) * GX), cdiv(Hs, GY), B);
+    const int gy = gather_tile_rows(B, Hs, Ws);
+    const dim3 gridDim3(cdiv(Ws, (NT / 64) * GX), cdiv(Hs, gy), B);
     const bool pairs = FC3D_GATHER_PAIRS && HWt % 2 == 0 && aligned16(grid) && (reinterpret_cast<uintptr_t>(g_out) & 7u) == 0;
-    if (pairs) {
-        FC3D_LAUNCH("bilinear_bwd_img_gather", bilinear_bwd_img_gather_kernel<true>, gridDim3, dim3(NT), 0, s, g_out, grid, index,
-                    B, (int)tap_index_groups(Ht, Wt), Hs, Ws, (unsigned)HWt, g_img, img, dot_partial);
-    } else {
-        FC3D_LAUNCH("bilinear_bwd_img_gather", bilinear_bwd_img_gather_kernel<false>, gridDim3, dim3(NT), 0, s, g_out, grid, index,
-                    B, (int)tap_index_groups(Ht, Wt), Hs, Ws, (unsigned)HWt, g_img, img, dot_partial);
+#define FC3D_GATHER_CASE(PAIRS_, GY_)                                                                                   \
+    if (pairs == PAIRS_ && gy == GY_) {                                                                                 \
+        FC3D_LAUNCH("bilinear_bwd_img_gather", (bilinear_bwd_img_gather_kernel<PAIRS_, GY_>), gridDim3, dim3(NT), 0, s, \
+                    g_out, grid, index, B, (int)tap_index_groups(Ht, Wt), Hs, Ws, (unsigned)HWt, g_img, img,           \
+                    dot_partial);                                                                                       \
+        return FC3D_OK;                                                                                                 \
     }
-    return FC3D_OK;
+#if FC3D_GATHER_GY
+    FC3D_GATHER_CASE(true, FC3D_GATHER_GY) FC3D_GATHER_CASE(false, FC3D_GATHER_GY)
+#else
+    FC3D_GATHER_CASE(true, 12) FC3D_GATHER_CASE(false, 12) FC3D_GATHER_CASE(true, 6) FC3D_GATHER_CASE(false, 6)
+    FC3D_GATHER_CASE(true, 4) FC3D_GATHER_CASE(false, 4)
+#endif
+#undef FC3D_GATHER_CASE
+    return FC3D_EINVAL;
 }
 
 extern "C" int fc3d_bilinear_bwd_img(void* stream, const float* g_out, const float* grid, const uint8_t* mask_u8,
@@ -1689,9 +1714,9 @@ extern "C" int fc3d_bilinear_bwd_img(void* stream, const float* g_out, const flo
     return launch_gather(s, g_out, grid, index, B, Hs, Ws, Ht, Wt, g_img, nullptr, nullptr);
 }
 
-extern "C" int fc3d_bilinear_bwd_img_dot_count(int Hs, int Ws) {
-    if (Hs <= 0 || Ws <= 0) return 0;
-    return cdiv(Ws, (NT / 64) * GX) * (NT / 64) * cdiv(Hs, GY);
+extern "C" int fc3d_bilinear_bwd_img_dot_count(int B, int Hs, int Ws) {
+    if (B <= 0 || Hs <= 0 || Ws <= 0) return 0;
+    return cdiv(Ws, (NT / 64) * GX) * (NT / 64) * cdiv(Hs, gather_tile_rows(B, Hs, Ws));
 }
 
 extern "C" int fc3d_bilinear_bwd_img_dot(void* stream, const float* g_out, const float* grid, int B, int Hs, int Ws,

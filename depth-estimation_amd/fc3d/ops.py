@@ -407,7 +407,7 @@ def _bilinear_bwd_img(g, grid, mask, B, Hs, Ws, C, Ht, Wt, index=None, img=None)
     gi = torch.empty((B, Hs, Ws, C), dtype=torch.float32, device=dev)
     if ready and C == 1 and img is not None and img.is_contiguous():
         # gather form + the per-tile sums of gi * img on the side (see _offer_grad_dot)
-        n = _lib.fc3d_bilinear_bwd_img_dot_count(Hs, Ws)
+        n = _lib.fc3d_bilinear_bwd_img_dot_count(B, Hs, Ws)
         partials = torch.empty((B, n), dtype=torch.float32, device=dev)
         with _on_device(dev):
             _check(_lib.fc3d_bilinear_bwd_img_dot(_stream(), g.data_ptr(), grid.data_ptr(), B, Hs, Ws, Ht, Wt,

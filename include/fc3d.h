@@ -36,7 +36,7 @@ extern "C" {
 #define FC3D_EALIGN (-3)     /* pointer not aligned to its element type */
 #define FC3D_ESCRATCH (-4)   /* problem larger than the library's static scratch buffer */
 
-#define FC3D_VERSION 211
+#define FC3D_VERSION 212
 
 int fc3d_version(void);
 const char *fc3d_status_string(int status);
@@ -204,9 +204,10 @@ int fc3d_bilinear_bwd_img(void *stream, const float *g_out, const float *grid, c
  * normalisation of img by one of its own statistics needs -- the inner product of the gradient it
  * has just formed with img, the image that was sampled (codePattern divides by the per-image
  * maximum, optics_pytorch.py:118-119; its backward needs sum(g * Ip_coded)): one partial per source
- * tile, dot_partial[b * n + t], n = fc3d_bilinear_bwd_img_dot_count(Hs, Ws), the sum over tile t of
- * g_img * img, each tile summed in a fixed order.  fc3d_code_pattern_bwd_dot takes them.        */
-int fc3d_bilinear_bwd_img_dot_count(int Hs, int Ws);
+ * tile, dot_partial[b * n + t], n = fc3d_bilinear_bwd_img_dot_count(B, Hs, Ws), the sum over tile t of
+ * g_img * img, each tile summed in a fixed order.  fc3d_code_pattern_bwd_dot takes them.  (The
+ * count depends on the batch as well: small problems are cut into shorter tiles.)               */
+int fc3d_bilinear_bwd_img_dot_count(int B, int Hs, int Ws);
 int fc3d_bilinear_bwd_img_dot(void *stream, const float *g_out, const float *grid, int B, int Hs, int Ws,
                               int Ht, int Wt, void *index, const float *img, float *g_img,
                               float *dot_partial);

@@ -378,7 +378,10 @@ def test_bilinear_golden(mods, golden, mode):
     # targets of more than 512 index groups (several scan rounds per workgroup): hits that pile up over the rounds
     # and are worked off once, and -- ten target pixels per source cell -- lists that fill up and are worked off
     # in between
-    (1, 300, 500, 700, 900, "smooth"), (1, 64, 128, 640, 1024, "zoom")])
+    (1, 300, 500, 700, 900, "smooth"), (1, 64, 128, 640, 1024, "zoom"),
+    # the source tiles are 4, 6 or 12 rows tall, by the number of workgroups the source images give: the cases
+    # above all take 4; two native-size images take 6, four take 12
+    (2, 800, 1200, 800, 1200, "jump"), (4, 800, 1200, 800, 1200, "smooth")])
 def test_image_gradient_gather_form(mods, B, Hs, Ws, Ht, Wt, kind):
     """d out / d img of the one-channel sampler in gather form (source tiles look up their samples
     in the tap index) against a float64 scatter_add of the four weighted taps: ragged sizes,

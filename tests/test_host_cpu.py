@@ -21,7 +21,7 @@ def test_cabi_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in fc3d.h but not exported"
     assert declared == set(_native.SIGNATURES), declared ^ set(_native.SIGNATURES)
-    assert lib.fc3d_version() == _native.ABI_VERSION == 211
+    assert lib.fc3d_version() == _native.ABI_VERSION == 212
     assert lib.fc3d_status_string(-1).decode().startswith("invalid")
     # argument validation happens before any device work
     assert lib.fc3d_visible_mask(None, None, 1, 4, 4, 0, None, None) == -1
@@ -67,7 +67,9 @@ def test_cabi_exports_every_declared_symbol():
     assert lib.fc3d_warp_project_splat(None, one, 0, 0, 0, 0, one, one, 0, 1, *big, one + 8, one, 0, one, one, None) == -2
     assert lib.fc3d_warp_sample(None, one, one, 0, 0, 0, 0, None, 1, 8, 8, one, 0, one, one + 8, None) == -1
     assert lib.fc3d_warp_sample(None, one, one, 0, 0, 0, 0, one, 1, *big, one, 0, one, one + 8, None) == -2
-    assert lib.fc3d_bilinear_bwd_img_dot_count(512, 512) == 8 * 43 and lib.fc3d_bilinear_bwd_img_dot_count(0, 5) == 0
+    assert lib.fc3d_bilinear_bwd_img_dot_count(32, 512, 512) == 8 * 43 and lib.fc3d_bilinear_bwd_img_dot_count(1, 0, 5) == 0
+    # small problems are cut into shorter tiles: the tallest of 12 / 6 / 4 rows that gives 1,024 workgroups, else 4
+    assert lib.fc3d_bilinear_bwd_img_dot_count(8, 512, 512) == 8 * 86 and lib.fc3d_bilinear_bwd_img_dot_count(1, 256, 256) == 4 * 64
     assert lib.fc3d_bilinear_bwd_img_dot(None, one, one + 8, 1, 8, 8, 8, 8, one + 8, None, one, one) == -1      # no image
     assert lib.fc3d_bilinear_bwd_img_dot(None, one, one + 8, 1, 8, 8, *big, one + 8, one, one, one) == -2
     assert lib.fc3d_code_pattern_bwd_dot_supported(5, 5, 1) == 1 and lib.fc3d_code_pattern_bwd_dot_supported(23, 23, 1) == 1
