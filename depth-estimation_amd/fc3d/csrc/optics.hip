@@ -296,14 +296,14 @@ __device__ __forceinline__ unsigned long long block_max_key(const unsigned long 
     return k;
 }
 
-// float4s per thread of the normalisation pass.  Every workgroup reduces all max keys of its image, so a
-// workgroup's share of the image has to outweigh them: 4 for ordinary images, 16 where an image has
-// thousands of keys (one per 16x16 tile of a 1024 x 1024 image: 32 KB of keys against 16 KB of pixels).
-constexpr int NORM_V_SMALL = 4;
-constexpr int NORM_V_LARGE = 16;
-constexpr int NORM_LARGE_KEYS = 2048;
+constexpr int NORM_V = 4;                 // float4s per thread of the normalisation pass
+// Every workgroup reduces all max keys of its image.  With thousands of them (one per 16x16 tile: 4,096 at
+// 1024 x 1024) that is a chain of dependent round trips per thread unless several loads are in flight.
+// Measured: 576 keys (three trips) are faster left alone (eight loads instead of three: +1.9 us at 32 x 512^2).
+constexpr int NORM_KEYS_PLAIN = 3 * NT;   // up to here: the plain loop
+constexpr int NORM_KEYS_FOUR = 4 * NT;    // up to here: four loads in flight (one trip); beyond: eight
 
-template <bool VEC, int NORM_V>
+template <bool VEC, int AHEAD>
 __global__ __launch_bounds__(NT) void code_pattern_norm_kernel(
     const float* __restrict__ raw, const unsigned long long* __restrict__ tilekey, int ntiles, int H, int W,
     float* __restrict__ out, float* __restrict__ max_out, int* __restrict__ argmax_out) {
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(NT) void code_pattern_norm_kernel(
             if (i < HW) v[j] = ld_pol<kNtNormLoad>(reinterpret_cast<const float4*>(raw + base + i));
         }
     }
-    const unsigned long long key = block_max_key<(NORM_V == NORM_V_LARGE ? 8 : 1)>(tilekey + (long)b * ntiles, ntiles, s_red);
+    const unsigned long long key = block_max_key<AHEAD>(tilekey + (long)b * ntiles, ntiles, s_red);
     const float m = key_to_float((uint32_t)(key >> 32));
     const float den = m + 1e-10f;
     const float rden = 1.0f / den;      // one rounding more than raw / den: far inside the fp tolerance
@@ -2011,10 +2011,10 @@ extern "C" int fc3d_code_pattern_norm(void* stream, const float* raw, const uint
     if ((long)B * H * W >= (1L << 31) || B > 65535) return FC3D_ERANGE;
     const int ntiles = keys_per_image;
     const bool vec = (((long)H * W) % 4 == 0) && aligned16(raw) && aligned16(out);
-    const bool large = ntiles >= NORM_LARGE_KEYS;
-    dim3 g(cdiv((long)H * W, NT * 4 * (large ? NORM_V_LARGE : NORM_V_SMALL)), B), blk(NT);
-    auto k = vec ? (large ? code_pattern_norm_kernel<true, NORM_V_LARGE> : code_pattern_norm_kernel<true, NORM_V_SMALL>)
-                 : (large ? code_pattern_norm_kernel<false, NORM_V_LARGE> : code_pattern_norm_kernel<false, NORM_V_SMALL>);
+    const int ahead = ntiles <= NORM_KEYS_PLAIN ? 1 : ntiles <= NORM_KEYS_FOUR ? 4 : 8;
+    dim3 g(cdiv((long)H * W, NT * 4 * NORM_V), B), blk(NT);
+    auto k = vec ? (ahead == 8 ? code_pattern_norm_kernel<true, 8> : ahead == 4 ? code_pattern_norm_kernel<true, 4> : code_pattern_norm_kernel<true, 1>)
+                 : (ahead == 8 ? code_pattern_norm_kernel<false, 8> : ahead == 4 ? code_pattern_norm_kernel<false, 4> : code_pattern_norm_kernel<false, 1>);
     FC3D_LAUNCH("code_pattern_norm", k, g, blk, 0, (hipStream_t)stream, raw, (const unsigned long long*)tilekey_u64,
                 ntiles, H, W, out, max_out, argmax_i32);
     return FC3D_OK;
