@@ -174,6 +174,28 @@ def test_c1_one_256_scene_against_the_oracle(env, monkeypatch, pattern_kind):
     assert rel_err_elem(ga[inner], gr[inner]) < TOL
 
 
+@pytest.mark.parametrize("B,count", [(4, 8 * 128), (8, 8 * 86), (16, 8 * 43)])
+def test_pattern_gradient_with_every_gather_tile_height(env, monkeypatch, B, count):
+    """The image-gradient gather cuts the source into tiles of 4, 6 or 12 rows by the size of the problem
+    (512 x 512: up to 4, 8, more images), and the per-tile sums of gradient x image it hands to codePattern's
+    backward follow: same bits twice, both backward functions take the hand-over, and the pattern gradient
+    agrees with the atomic form followed by the two-launch backward."""
+    ops = env["ops"]
+    wl, cfg, t = load(env, "C2", monkeypatch, B=B, pattern_kind="uniform")
+    assert ops._lib.fc3d_bilinear_bwd_img_dot_count(B, cfg["H"], cfg["W"]) == count
+    taken = ops.handover_stats["taken"]
+    a = run(env, t, cfg["L"])[4]
+    a2 = run(env, t, cfg["L"])[4]
+    assert ops.handover_stats["taken"] - taken == 2
+    assert torch.equal(a, a2)
+    old = ops.set_image_gradient_mode("atomic")
+    try:
+        b = run(env, t, cfg["L"])[4]
+    finally:
+        ops.set_image_gradient_mode(old)
+    assert float((a - b).abs().max()) < 1e-5 * float(b.abs().max())
+
+
 def test_c4_large_kernels(env, monkeypatch):
     """1024x1024, 41 layers, 23x23 and 33x33 PSFs (LDS holds only the layers a tile touches)."""
     G, O, synth, orc = env["G"], env["O"], env["synth"], env["orc"]
