@@ -16,6 +16,8 @@ of 4, 60 or 64, single rows and columns), a layer count, a PSF size (odd 1..33, 
   re-projection    the one-kernel chain and the loss kernels against the composed operators
   operators        bilinear_sampler (1-4 channels, both gradients) and coord_transform (arbitrary matrices, both
                    gradients) against the oracle's autograd
+  chain            codePattern -> warp_p2c -> backward to the pattern: gather form + hand-over against atomic form +
+                   two-launch backward, same bits twice, the capture against the oracle
   image gradient   the gather form and the atomic form of the sampler's image gradient against a float64 scatter,
                    for smooth, magnifying, shrinking, discontinuous and random sampling grids
 
@@ -546,6 +548,80 @@ def case_operators(rs, env):
     return desc, bad
 
 
+def case_chain(rs, env):
+    """codePattern -> warp_p2c -> backward to the pattern, the step of the benchmark, for drawn shapes and PSFs:
+    the default backward (gather form; the sampler hands sum(gradient x image) to codePattern's backward where
+    the PSF size has a one-launch backward) twice for equal bits, against the atomic form followed by the
+    two-launch backward, and the forward against the oracle (the capture to 1e-4; it is handed the library's
+    inverse pose)."""
+    G, O, synth, orc, ops = env["G"], env["O"], env["synth"], env["orc"], env["ops"]
+    B = int(rs.randint(1, 5))
+    H, W = draw_size(rs)
+    if rs.uniform() < 0.25:
+        H, W = int(rs.randint(100, 300)), int(rs.randint(100, 520))
+    L = int(rs.choice([21, 41]))
+    K = int(rs.choice([0, 3, 5, 5, 7, 9, 13]))
+    theta = float(rs.choice([1.0, 3.0, 20.0]))
+    desc = dict(op="chain", B=B, H=H, W=W, L=L, K=K, theta=theta)
+    sc = synth.make_scene(B, H, W, int(rs.randint(1 << 30)), theta_deg=theta)
+    cx, cy = W / 2, H / 2
+
+    def get_intrinsic(Bn, device="cuda"):
+        Km = np.diag([1666.67, 1666.67, 1, 1])
+        Km[0][2], Km[1][2] = cx, cy
+        return torch.from_numpy(Km).float().to(device).unsqueeze(0).repeat(Bn, 1, 1)
+
+    bad = []
+    old_K, keep = G.get_intrinsic, O.PSFs_np
+    G.get_intrinsic = get_intrinsic
+    psfs = synth.make_psfs(L, K, "disc") if K else None
+    if K:
+        O.PSFs_np = psfs
+    try:
+        rays = G.pixel_to_ray_array(W, H)
+        z_p, z_c, pose = dev(sc["z_p"]), dev(sc["z_c"]), dev(sc["pose_p2c"])
+        cp = G.points_in_camera_coords(z_p, rays).permute(0, 3, 1, 2)
+        cc = G.points_in_camera_coords(z_c, rays).permute(0, 3, 1, 2)
+        p0 = rs.uniform(0.2, 1, (B, H, W, 1)).astype(np.float32)
+        gg = dev(rs.uniform(-1, 1, (B, H, W, 1)).astype(np.float32))
+
+        def run():
+            p = dev(p0).requires_grad_(True)
+            Ip = O.codePattern(p, z_p, is_conv_psf=bool(K), n_layers=L)
+            Ic, gp, gc = G.warp_p2c(Ip, cp, cc, pose)
+            Ic.backward(gg)
+            return p.grad, Ic.detach(), gp, gc
+
+        a, Ic, gp, gc = run()
+        a2 = run()[0]
+        if not torch.equal(a, a2):
+            bad.append(("not the same bits twice", float((a - a2).abs().max())))
+        old = ops.set_image_gradient_mode("atomic")
+        try:
+            b = run()[0]
+        finally:
+            ops.set_image_gradient_mode(old)
+        e = float((a - b).abs().max())
+        if not e <= 2e-5 * max(float(b.abs().max()), 1e-30):
+            bad.append(("gather + hand-over vs atomic + two launches", e, float(b.abs().max())))
+        # forward against the oracle
+        _, _, inv = ops.pose_transforms(pose, None, want_a=True)
+        pc = t(np.repeat(p0, L, axis=-1))
+        Ip_r = orc.codePattern(pc, t(sc["z_p"]), psfs, bool(K))
+        Ic_r, gp_r, gc_r = orc.warp_p2c(Ip_r, orc.z2pointcloud(t(sc["z_p"])), orc.z2pointcloud(t(sc["z_c"])),
+                                        t(sc["pose_p2c"]), cx, cy, pose_c2p=inv.cpu())
+        # (grids that differ in the host product's last points: see case_warp; in a one-row or one-column image both
+        # corners of every sample clamp onto the same pixel with weights that cancel: the capture is rounding noise)
+        if (min(H, W) > 1 and np.array_equal(gc.cpu().numpy(), gc_r.numpy())
+                and np.array_equal(gp.cpu().numpy(), gp_r.numpy())):
+            e = rel_err(Ic.cpu().numpy(), Ic_r.numpy())
+            if not e < TOL:
+                bad.append(("Ic", e))
+    finally:
+        G.get_intrinsic, O.PSFs_np = old_K, keep
+    return desc, bad
+
+
 def environment():
     import geometry_pytorch as G
     import optics_pytorch as O
@@ -562,7 +638,7 @@ def sweep(cases, seed, env=None, verbose=False, only=None):
     failures = []
     for i in range(cases):
         fn = (case_code_pattern, case_code_pattern, case_warp, case_code_pattern, case_capture, case_warp,
-              case_gather, case_reproject, case_operators)[i % 9]
+              case_gather, case_reproject, case_operators, case_chain)[i % 10]
         sub = np.random.RandomState(int(rs.randint(1 << 30)))
         if only and i not in only:
             continue
